@@ -1,0 +1,288 @@
+"""CPU oracle for the YOLOv3 inference hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (PyTorch fp32 CPU ops + numpy) of the reference
+algorithm for the path  Darknet-53 forward -> YOLO head decode -> IOU + greedy NMS.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it, and only as the checker / the reported CPU baseline.  Nothing in
+``yolo_v3_amd/`` imports it; the product path has no CPU fallback.
+
+Parity pin: the reference ships no tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference itself,
+produced in the build container by ``oracle/make_golden.py`` (which imports
+``/root/reference``) and committed as fixtures under ``tests/golden/``;
+``tests/test_oracle_golden.py`` replays them.
+
+It is written as pure functions over a ``state_dict`` (reference key names) rather
+than as nn.Modules, citing the reference lines each function follows.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+DEFAULT_ANCHORS = [10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326]
+BLOCKS = (1, 2, 8, 8, 4)
+
+
+# --------------------------------------------------------------------------- weights
+def read_darknet_file(path):
+    """reference darknet.py:265-271: 5 x int32 header, then a float32 stream."""
+    with open(path, "rb") as fp:
+        header = np.fromfile(fp, dtype=np.int32, count=5)
+        stream = np.fromfile(fp, dtype=np.float32)
+    return header, stream
+
+
+def _cbr_keys(prefix):
+    return [prefix + ".bn.bias", prefix + ".bn.weight", prefix + ".bn.running_mean",
+            prefix + ".bn.running_var", prefix + ".conv.weight"]
+
+
+def conv_prefixes(num_class=80):
+    """(prefix, cin, cout, k, has_bn) in the order reference darknet.py:292-303 visits the convs."""
+    out = [("feature.mlist.0", 3, 32, 3, True)]
+    idx, c = 1, 32
+    for nblk in BLOCKS:
+        out.append(("feature.mlist.%d" % idx, c, 2 * c, 3, True)); idx += 1
+        c *= 2
+        for _ in range(nblk):
+            out.append(("feature.mlist.%d.conv1" % idx, c, c // 2, 1, True))
+            out.append(("feature.mlist.%d.conv2" % idx, c // 2, c, 3, True))
+            idx += 1
+    nout_head = 3 * (5 + num_class)
+
+    def branch(pre, nin, n):
+        cin = nin
+        for i in range(3):
+            out.append(("%s.mlist.%d" % (pre, 2 * i), cin, n, 1, True))
+            out.append(("%s.mlist.%d" % (pre, 2 * i + 1), n, 2 * n, 3, True))
+            cin = 2 * n
+        out.append(("%s.mlist.6" % pre, cin, nout_head, 1, False))
+
+    branch("pre_det1", 1024, 512)
+    out.append(("up1.conv", 512, 256, 1, True))
+    branch("pre_det2", 768, 256)
+    out.append(("up2.conv", 256, 128, 1, True))
+    branch("pre_det3", 384, 128)
+    return out
+
+
+def state_dict_from_stream(stream, num_class=80):
+    """reference darknet.py:254-290: slice the float stream into parameters, cfg order."""
+    sd, p = {}, 0
+    for prefix, cin, cout, k, has_bn in conv_prefixes(num_class):
+        nw = cout * cin * k * k
+        if has_bn:
+            for key in _cbr_keys(prefix)[:4]:
+                sd[key] = torch.from_numpy(stream[p:p + cout].copy()); p += cout
+            sd[prefix + ".conv.weight"] = torch.from_numpy(stream[p:p + nw].copy()).view(cout, cin, k, k); p += nw
+        else:
+            sd[prefix + ".bias"] = torch.from_numpy(stream[p:p + cout].copy()); p += cout
+            sd[prefix + ".weight"] = torch.from_numpy(stream[p:p + nw].copy()).view(cout, cin, k, k); p += nw
+    return sd, p
+
+
+# --------------------------------------------------------------------------- conv trunk
+def cbr(sd, prefix, x, stride=1):
+    """reference darknet.py:27-44: conv(no bias, pad=(k-1)//2) -> BatchNorm2d(eval) -> LeakyReLU(0.1)."""
+    w = sd[prefix + ".conv.weight"]
+    y = F.conv2d(x, w, None, stride, (w.shape[2] - 1) // 2)
+    y = F.batch_norm(y, sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"],
+                     sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], False, 0.1, 1e-5)
+    return F.leaky_relu(y, 0.1)
+
+
+def backbone(sd, x, taps=None):
+    """reference darknet.py:72-88 + 46-53.  Returns (out, route36 [52x52x256], route61 [26x26x512])."""
+    x = cbr(sd, "feature.mlist.0", x)
+    if taps is not None: taps.append(("feature.mlist.0", x))
+    idx, routes = 1, {}
+    for nblk in BLOCKS:
+        x = cbr(sd, "feature.mlist.%d" % idx, x, stride=2)
+        if taps is not None: taps.append(("feature.mlist.%d" % idx, x))
+        idx += 1
+        for _ in range(nblk):
+            p = "feature.mlist.%d" % idx
+            h = cbr(sd, p + ".conv1", x)
+            if taps is not None: taps.append((p + ".conv1", h))
+            x = x + cbr(sd, p + ".conv2", h)                       # darknet.py:53
+            if taps is not None: taps.append((p + ".conv2", x))
+            idx += 1
+        routes[idx - 1] = x
+    # darknet.py:180-181: cfg idx 61 -> mlist[23], cfg idx 36 -> mlist[14]
+    return x, routes[14], routes[23]
+
+
+def predet(sd, prefix, x, taps=None):
+    """reference darknet.py:107-127.  Returns (head logits NCHW, output of mlist[4])."""
+    route = None
+    for i in range(6):
+        x = cbr(sd, "%s.mlist.%d" % (prefix, i), x)
+        if taps is not None: taps.append(("%s.mlist.%d" % (prefix, i), x))
+        if i == 4:
+            route = x                                               # darknet.py:185 addCachedOut(-3)
+    logits = F.conv2d(x, sd[prefix + ".mlist.6.weight"], sd[prefix + ".mlist.6.bias"])
+    if taps is not None: taps.append((prefix + ".mlist.6", logits))
+    return logits, route
+
+
+def upsample_cat(sd, prefix, head, tail, taps=None):
+    """reference darknet.py:159-162: 1x1 cbr, nearest x2, cat((up, tail), dim=1)."""
+    out = cbr(sd, prefix + ".conv", head)
+    if taps is not None: taps.append((prefix + ".conv", out))
+    out = F.interpolate(out, scale_factor=2, mode="nearest")
+    return torch.cat((out, tail), 1)
+
+
+def head_logits(sd, x, taps=None):
+    """Conv trunk only: the three head logit maps [B,255,h,w] (reference darknet.py:198-223)."""
+    feat, r36, r61 = backbone(sd, x, taps)
+    l1, h1 = predet(sd, "pre_det1", feat, taps)
+    l2, h2 = predet(sd, "pre_det2", upsample_cat(sd, "up1", h1, r61, taps), taps)
+    l3, _ = predet(sd, "pre_det3", upsample_cat(sd, "up2", h2, r36, taps), taps)
+    return l1, l2, l3
+
+
+# --------------------------------------------------------------------------- decode
+def decode(x, anchors_all, anchors_mask, img_dim, num_class=80):
+    """reference yololayer.py:31-59,97-105 (inference branch), same op order.
+
+    x [B, 3*(5+C), H, W] -> [B, H*W*3, 5+C]; row = (y*W + x)*3 + a; cols cx,cy,w,h,conf,cls...
+    """
+    nB, nA = x.shape[0], len(anchors_mask)
+    nH, nW = x.shape[2], x.shape[3]
+    attrib = 5 + num_class
+    stride = img_dim[1] / nH                                         # yololayer.py:36 (python float)
+    pairs = [(anchors_all[i], anchors_all[i + 1]) for i in range(0, len(anchors_all), 2)] \
+        if not isinstance(anchors_all[0], (tuple, list)) else list(anchors_all)
+    anc_all = torch.FloatTensor(pairs) / stride                      # :37
+    anc = anc_all[list(anchors_mask)]                                # :38
+    preds = x.view(nB, nA, attrib, nH, nW).permute(0, 1, 3, 4, 2).contiguous()   # :42
+    xy = preds[..., :2].sigmoid()                                    # :45
+    wh = preds[..., 2:4]
+    conf = preds[..., 4].sigmoid()                                   # :47
+    cls = preds[..., 5:].sigmoid()                                   # :48
+    gx = torch.arange(nW).repeat(nH, 1).unsqueeze(2)                 # :51
+    gy = torch.arange(nH).repeat(nW, 1).t().unsqueeze(2)             # :52
+    gxy = torch.cat((gx, gy), 2).float()
+    manc = anc.view(1, nA, 1, 1, 2).repeat(1, 1, nH, nW, 1)
+    box = torch.empty(preds[..., :4].shape)
+    box[..., :2] = xy + gxy                                          # :58
+    box[..., 2:4] = wh.exp() * manc                                  # :59
+    out = torch.cat((box * stride, conf.unsqueeze(4), cls), 4)       # :98-100
+    return out.permute(0, 2, 3, 1, 4).contiguous().view(nB, nA * nH * nW, attrib)   # :104
+
+
+def yolonet_forward(sd, x, anchors=DEFAULT_ANCHORS, num_class=80):
+    """reference darknet.py:198-231 with target=None: returns (det1, det2, det3)."""
+    img_dim = (x.shape[3], x.shape[2])                               # darknet.py:199
+    l1, l2, l3 = head_logits(sd, x)
+    return (decode(l1, anchors, (6, 7, 8), img_dim, num_class),
+            decode(l2, anchors, (3, 4, 5), img_dim, num_class),
+            decode(l3, anchors, (0, 1, 2), img_dim, num_class))
+
+
+# --------------------------------------------------------------------------- geometry
+def cxcywh_to_x1y1x2y2(box):
+    """reference boundingbox.py:25-29 (returns a new tensor)."""
+    x1, x2 = box[..., 0] - box[..., 2] / 2, box[..., 0] + box[..., 2] / 2
+    y1, y2 = box[..., 1] - box[..., 3] / 2, box[..., 1] + box[..., 3] / 2
+    return torch.stack((x1, y1, x2, y2), -1)
+
+
+def iou_matrix(b):
+    """reference utils.py:98-119: all-pairs IOU of x1y1x2y2 boxes, no +1, no eps."""
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    ix1 = torch.max(x1[:, None], x1[None, :])
+    iy1 = torch.max(y1[:, None], y1[None, :])
+    ix2 = torch.min(x2[:, None], x2[None, :])
+    iy2 = torch.min(y2[:, None], y2[None, :])
+    inter = torch.clamp(ix2 - ix1, min=0) * torch.clamp(iy2 - iy1, min=0)
+    area = (x2 - x1) * (y2 - y1)
+    union = area[None, :] + area[:, None] - inter                    # utils.py:116 (area_j + area_i) - inter
+    return inter / union
+
+
+def bbox_iou(b1, b2, mode="x1y1x2y2"):
+    """reference utils.py:122-146: rectangular IOU [n1,n2], two box formats."""
+    if mode == "cxcywh":
+        b1 = cxcywh_to_x1y1x2y2(b1)
+        b2 = cxcywh_to_x1y1x2y2(b2)
+    ix1 = torch.max(b1[:, None, 0], b2[None, :, 0])
+    iy1 = torch.max(b1[:, None, 1], b2[None, :, 1])
+    ix2 = torch.min(b1[:, None, 2], b2[None, :, 2])
+    iy2 = torch.min(b1[:, None, 3], b2[None, :, 3])
+    inter = torch.clamp(ix2 - ix1, min=0) * torch.clamp(iy2 - iy1, min=0)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    return inter / (a1[:, None] + a2[None, :] - inter)
+
+
+# --------------------------------------------------------------------------- post-processing
+def _greedy_keep(over):
+    """Greedy scan of reference utils.py:180-190 on a boolean [n,n] matrix (True = IOU > thr).
+
+    A box whose diagonal entry is False (zero-area -> NaN self-IOU, or thr >= 1) is skipped:
+    it is neither emitted nor allowed to suppress (utils.py:182).
+    """
+    over = over.numpy().copy()
+    n = over.shape[0]
+    alive = over.diagonal().copy()
+    keep = []
+    for i in range(n):
+        if not alive[i]:
+            continue
+        keep.append(i)
+        sup = over[i, i + 1:] & alive[i + 1:]
+        alive[i + 1:][sup] = False
+    return keep
+
+
+def postprocess(detections, num_classes, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True):
+    """reference utils.py:226-258 + 148-224.  Does not mutate its argument (the reference does
+    when handed a CPU tensor, utils.py:227-233).  Returns ``[]`` or a list of B tensors, each
+    ``[n,7] = x1,y1,x2,y2,conf,score,cls`` or an empty ``torch.Tensor()`` (shape (0,)).
+    """
+    det = detections.detach().cpu().float().clone()
+    det[..., :4] = cxcywh_to_x1y1x2y2(det[..., :4])                  # utils.py:230
+    det[..., 5:5 + num_classes] = det[..., 5:5 + num_classes] * det[..., 4].unsqueeze(-1)   # :233
+    scores = det[..., 5:5 + num_classes]
+    if is_eval:
+        index = (scores > obj_conf_thr).nonzero()                    # :238
+    else:
+        mx, arg = torch.max(scores, -1)                              # :242 (first index wins ties)
+        m = mx > obj_conf_thr
+        if not m.any():
+            return []                                                # :248
+        index = torch.cat((m.nonzero(), arg[m].unsqueeze(-1)), -1)
+    if len(index) == 0:
+        return []                                                    # :251
+    results = []
+    for b in range(det.shape[0]):
+        sel = index[index[:, 0] == b]
+        if len(sel) == 0:
+            results.append(torch.Tensor())                           # :153-158
+            continue
+        if not use_nms:                                              # utils.py:204-224
+            rows = det[b, sel[:, 1]]
+            prob = rows[torch.arange(len(sel)), 5 + sel[:, 2]]
+            results.append(torch.cat((rows[:, :5], prob[:, None], sel[:, 2].float()[:, None]), -1))
+            continue
+        parts = []
+        for c in sel[:, 2].unique():                                 # ascending class ids, utils.py:161
+            rows = det[b, sel[sel[:, 2] == c][:, 1]]
+            order = torch.sort(rows[:, 5 + c], descending=True, stable=True)[1]   # :171 (stable here)
+            rows = rows[order]
+            keep = _greedy_keep(iou_matrix(rows[:, :4]) > nms_thr)   # :175-190
+            rows = rows[keep].view(-1, 5 + num_classes)
+            parts.append(torch.cat((rows[:, :5], rows[:, 5 + c].view(-1, 1),
+                                    torch.full((len(rows), 1), float(c))), -1))    # :193-197
+        results.append(torch.cat(parts, 0) if parts else torch.Tensor())
+    return results
+
+
+def detect(sd, imgs, num_classes=80, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
+           anchors=DEFAULT_ANCHORS):
+    """The caller idiom of reference test.py:35-36 / evaluate.py:201-204."""
+    with torch.no_grad():
+        d1, d2, d3 = yolonet_forward(sd, imgs, anchors, num_classes)
+        return postprocess(torch.cat((d1, d2, d3), 1), num_classes, obj_conf_thr, nms_thr, is_eval, use_nms)

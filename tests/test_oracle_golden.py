@@ -1,0 +1,97 @@
+"""Pin the CPU oracle (oracle/oracle_cpu.py) against outputs of the reference itself.
+
+The fixtures in tests/golden/ were produced by oracle/make_golden.py, which imports
+/root/reference in the build container.  These tests run anywhere (no GPU, no reference).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_cpu as oc
+from yolo_v3_amd import synth
+
+ANCHORS = oc.DEFAULT_ANCHORS
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_stream_slicing_matches_reference_loader(golden_dir, sw1_stream):
+    g = json.load(open(os.path.join(golden_dir, "weights_roundtrip.json")))
+    assert sha(sw1_stream) == g["stream_sha256"]            # generator is bit-reproducible
+    sd, ptr = oc.state_dict_from_stream(sw1_stream)
+    assert ptr == g["ptr"] == 62001757
+    assert g["n_convs"] == 75 and len(oc.conv_prefixes()) == 75
+    for k, h in g["sha256"].items():
+        assert sha(sd[k].numpy()) == h, k
+        assert list(sd[k].shape) == g["shapes"][k]
+
+
+def test_decode_bitwise_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    for key in ("h13_s416", "h26_s416", "h52_s416", "h19_s608", "h76_s608"):
+        h, size, step, seed, *mask = [int(v) for v in g[key + "_cfg"]]
+        logits = synth.uniform(seed, 7, 2 * 255 * h * h, -6.0, 6.0).reshape(2, 255, h, h)
+        out = oc.decode(torch.from_numpy(logits.copy()), ANCHORS, mask, (size, size)).numpy()
+        assert np.array_equal(out[:, ::step], g[key + "_out"]), key
+        assert sha(out) == bytes(g[key + "_sha"]).hex(), key
+
+
+def test_iou_bitwise_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "iou.npz"))
+    xyxy, b2, cxcywh = (torch.from_numpy(g[k]) for k in ("xyxy", "b2", "cxcywh"))
+    assert np.array_equal(oc.iou_matrix(xyxy).numpy(), g["iou_vec"], equal_nan=True)
+    assert np.array_equal(oc.bbox_iou(xyxy, b2).numpy(), g["bbox_iou_xyxy"], equal_nan=True)
+    assert np.array_equal(oc.bbox_iou(cxcywh, cxcywh[:40], "cxcywh").numpy(), g["bbox_iou_cxcywh"], equal_nan=True)
+    assert np.array_equal(oc.cxcywh_to_x1y1x2y2(cxcywh).numpy(), g["to_xyxy"])
+
+
+def _check_result_list(res, g, name):
+    n = int(g[name + "_islist"][0])
+    assert len(res) == n, name
+    for i, r in enumerate(res):
+        exp = g["%s_out%d" % (name, i)]
+        assert tuple(r.shape) == tuple(exp.shape), (name, i, r.shape, exp.shape)
+        assert np.array_equal(r.numpy(), exp), (name, i)
+
+
+def test_postprocess_bitwise_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    for name in [str(n) for n in g["names"]]:
+        ct, nt, ev, nms = g[name + "_cfg"]
+        res = oc.postprocess(torch.from_numpy(g[name + "_in"].copy()), 80, float(ct), float(nt), bool(ev), bool(nms))
+        _check_result_list(res, g, name)
+
+
+@pytest.mark.parametrize("name", ["dog416", "u416", "u608"])
+def test_end_to_end_vs_reference(golden_dir, sw1_stream, name):
+    """Same torch CPU ops on the same weights: the functional restatement reproduces the
+    reference's detections and final boxes bitwise."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    sd, _ = oc.state_dict_from_stream(sw1_stream)
+    if name == "dog416":
+        x = torch.from_numpy(g["dog_u8"].astype(np.float32) / np.float32(255.0)).permute(2, 0, 1).unsqueeze(0).contiguous()
+    else:
+        b, s = {"u416": (2, 416), "u608": (1, 608)}[name]
+        x = torch.from_numpy(synth.images(b, s, int(g[name + "_seed"][0])))
+    with torch.no_grad():
+        dets = torch.cat(oc.yolonet_forward(sd, x), 1)
+    rows = g[name + "_rows"]
+    np.testing.assert_allclose(dets[:, rows].numpy(), g[name + "_dets_rows"], rtol=2e-6, atol=2e-6)
+    res = oc.postprocess(dets, 80, 0.5, 0.4)
+    assert len(res) == int(g[name + "_nres"][0])
+    for i, r in enumerate(res):
+        exp = g["%s_boxes%d" % (name, i)]
+        assert tuple(r.shape) == tuple(exp.shape)
+        np.testing.assert_allclose(r.numpy(), exp, rtol=2e-6, atol=2e-6)
+    if name == "dog416":
+        ct, nt = g["dog416_eval_cfg"]
+        ev = oc.postprocess(dets, 80, float(ct), float(nt), True, True)
+        assert tuple(ev[0].shape) == tuple(g["dog416_eval_boxes0"].shape)
+        np.testing.assert_allclose(ev[0].numpy(), g["dog416_eval_boxes0"], rtol=2e-6, atol=2e-6)
