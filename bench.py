@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: YOLOv3 inference hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--size 416]
+
+A step = one pass of the whole hot path over one batch of synthetic images that already live in
+HBM: 75 convolutions (Darknet-53 + heads) -> 3-scale decode -> confidence filter -> per-class
+greedy NMS -> final [B,cap,7] boxes copied to pinned host memory (asynchronously).  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank runs its own shard of the global
+batch (weak scaling: --batch images PER GPU), and each step ends with the RCCL all-gather of the
+final boxes.  Rank 0 prints ONE JSON line.
+
+`roofline` is for the dominant kernel family, the fp32 implicit-GEMM convolution
+(conv_igemm_f32_kernel, 74 launches per step): algorithmic FLOPs of those 74 convs for the batch
+divided by the time of their launch sequence, measured with HIP events on the launch stream in every
+timed step, against the 157.3 TFLOP/s fp32 MFMA peak.  `cpu_baseline` is the CPU oracle (torch fp32
+CPU ops, same weights/inputs) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch                       # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def cpu_baseline(stream, size, n_img=8):
+    """Oracle (CPU restatement of the reference path) on the host cores: forward + post-processing."""
+    from oracle import oracle_cpu as oc
+    from yolo_v3_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd, _ = oc.state_dict_from_stream(stream)
+    x = torch.from_numpy(synth.images(n_img, size, 1))
+    best = None
+    t_all = time.perf_counter()
+    for it in range(3):                                   # 1 warm-up + 2 timed, stop early if slow
+        t0 = time.perf_counter()
+        oc.detect(sd, x, 80, 0.5, 0.4)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+        if time.perf_counter() - t_all > 25 and best is not None:
+            break
+    return {"value": round(n_img / best, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d images %dx%d, forward+decode+NMS, torch fp32 CPU ops, best of %d after 1 warm-up"
+                      % (n_img, size, size, max(1, it))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--conf", type=float, default=0.5)
+    ap.add_argument("--nms", type=float, default=0.4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from yolo_v3_amd import YoloNet, WeightManager, Detector, synth, arch, dist as ydist, _ffi
+
+    rank, local, world = ydist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dtype = {"f32": _ffi.F32, "bf16": _ffi.BF16}[args.dtype]
+
+    # ---- model + data (synthetic SW-1 weights, synthetic scenes; both bit-reproducible)
+    stream = synth.weight_stream()
+    net = YoloNet((args.size, args.size)).eval()
+    assert WeightManager(net).load_stream(stream) == stream.size
+    net = net.to(dev)
+    B = args.batch
+    lo, _ = ydist.shard_range(B * world, rank, world)
+    base = synth.images(min(B, 16), args.size, 1000 + lo)                 # 16 distinct scenes per rank, tiled
+    x = torch.from_numpy(base).to(dev).repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous()
+
+    det = Detector(net, B, args.size, args.size, args.conf, args.nms, dtype=dtype)
+    eng, plan = det.engine, det.plan
+    cap = det.pp.cap
+    host_boxes = torch.empty((B * world, min(cap, 512), 7), dtype=torch.float32).pin_memory()
+    host_counts = torch.empty((B * world,), dtype=torch.int32).pin_memory()
+
+    conv_ev = []
+
+    def step(timed):
+        # conv section bracketed by events on the launch stream (torch's current stream)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lib = _ffi.lib()
+        s = _ffi.stream_ptr()
+        p0 = eng.packed[0]
+        _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
+                                 plan.conv0_out.data_ptr(), B, plan.H, plan.W, dtype, s))
+        if timed:
+            e0.record()
+        _ffi.check(lib.yv3_conv2d_sequence(plan.descs, plan.n_desc, s))
+        if timed:
+            e1.record()
+            conv_ev.append((e0, e1))
+        eng.run_decode(plan, det.dets)
+        boxes, counts = det.pp.run_sync_free(det.dets, args.conf, args.nms, False, True, prob=True)
+        kept = counts[B:]
+        if world > 1:
+            boxes, kept = ydist.gather_boxes(boxes[:, :host_boxes.shape[1]].contiguous(), kept)
+        else:
+            boxes = boxes[:, :host_boxes.shape[1]]
+        host_boxes.copy_(boxes, non_blocking=True)
+        host_counts.copy_(kept, non_blocking=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        fence()
+        elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    conv_ms = sum(a.elapsed_time(b) for a, b in conv_ev) / len(conv_ev)
+    specs = arch.conv_specs()
+    hw = arch.conv_output_hw(args.size)
+    macs = [h * w * sp.cout * sp.cin * sp.k * sp.k for sp, (h, w) in zip(specs, hw)]
+    flops_all = 2.0 * sum(macs) * B
+    flops_igemm = 2.0 * sum(macs[1:]) * B                      # the 74 implicit-GEMM launches
+    achieved = flops_igemm / (conv_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.dtype]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        out = {
+            "metric": "images/sec (YOLOv3 forward + decode + NMS, %dx%d, bs=%d per GPU)" % (args.size, args.size, B),
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_img": round(ms_per_step / B, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%dx%d bs=%d per GPU, synthetic scenes, SW-1 synthetic weights, conf=%.2f nms=%.2f"
+                                   % (args.size, args.size, B, args.conf, args.nms),
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "boxes_kept_first_images": host_counts[:4].tolist()},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_%s_kernel (74 launches/step)" % args.dtype,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "conv_ms_per_step": round(conv_ms, 4), "launches": plan.n_desc,
+                         "avg_launch_ms": round(conv_ms / plan.n_desc, 5),
+                         "flop_per_launch_avg": flops_igemm / plan.n_desc,
+                         "end_to_end_frac": round(flops_all / (ms_per_step * 1e-3) / 1e12 / peak, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(stream, args.size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

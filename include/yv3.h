@@ -1,0 +1,175 @@
+/*
+ * yv3.h -- C-ABI of libyv3.so: the MI355X (gfx950) YOLOv3 inference hot path.
+ *
+ * The reference (ydixon/yolo_v3) has no FFI: its boundary is the Python module surface
+ * (darknet.py / yololayer.py / utils.py).  The Python package yolo_v3_amd mirrors that
+ * surface and calls ONLY the functions below (via ctypes, see yolo_v3_amd/_ffi.py).  Each
+ * entry point names the reference call site it replaces (file:line in /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative YV3_E* code on a bad argument, or a
+ *     positive hipError_t when a launch fails;
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch caching allocator) unless
+ *     the name says host; nothing here allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and nothing else;
+ *   - activations are NHWC ("channels last"), fp32 (dtype 0) or bf16 (dtype 1); accumulation,
+ *     BN scale/shift, decode and post-processing are always fp32;
+ *   - no global mutable state: concurrent calls on distinct streams/workspaces are safe.
+ */
+#ifndef YV3_H
+#define YV3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YV3_VERSION 100          /* 0.1.0 */
+
+#define YV3_EINVAL   (-1)        /* null pointer / non-positive dimension                  */
+#define YV3_ESHAPE   (-2)        /* shape not supported by the kernel family (see function) */
+#define YV3_EWORKSPACE (-3)      /* workspace too small                                     */
+#define YV3_EDTYPE   (-4)        /* unknown dtype code                                      */
+
+#define YV3_F32  0
+#define YV3_BF16 1
+
+#define YV3_ACT_LINEAR 0
+#define YV3_ACT_LEAKY  1         /* LeakyReLU(0.1), reference darknet.py:41 */
+
+int yv3_version(void);
+const char* yv3_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight preparation (one-off, at load time).  Replaces nothing on the reference's forward
+ * path; it turns the parameters WeightManager loads (darknet.py:279-290) into kernel layout.
+ * ------------------------------------------------------------------------------------------ */
+
+/* OIHW fp32 [cout][cin][k][k]  ->  K-major [cout_pad][k][k][cin] in `dtype`; rows >= cout are 0. */
+int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin, int k,
+                         int cout_pad, int dtype, void* stream);
+
+/* Eval-mode BatchNorm2d (darknet.py:39, eps=1e-5) as per-channel scale/shift:
+ * alpha = gamma / sqrt(var + eps), beta = bias - mean * alpha. */
+int yv3_fold_bn(const float* gamma, const float* bias, const float* mean, const float* var,
+                float eps, float* alpha, float* beta, int channels, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions.  Replace conv_bn_relu.forward (darknet.py:43-44), res_layer.forward
+ * (darknet.py:52-53), the plain head Conv2d (darknet.py:118) and UpsampleGroup's
+ * interpolate+cat (darknet.py:161-162).
+ * ------------------------------------------------------------------------------------------ */
+
+/* First layer, feature.mlist.0: 3 -> 32 channels, 3x3, stride 1, pad 1, + BN + leaky.
+ * x is the caller's NCHW fp32 image batch [B,3,H,W] (values in [0,1]); y is NHWC [B,H,W,32].
+ * w_tap_major is the OIHW weight permuted to [cin][kh][kw][cout] = [27][32] fp32;
+ * alpha/beta from yv3_fold_bn. */
+int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
+              void* y_nhwc, int B, int H, int W, int out_dtype, void* stream);
+
+typedef struct yv3_conv_desc {
+    const void*  x;         /* NHWC [B,H,W,cin] -- or, when cin_up > 0, the LOW-resolution map
+                               [B,H/2,W/2,cin_up] that is nearest-x2 upsampled on the fly      */
+    const void*  x2;        /* cin_up > 0 only: route tail NHWC [B,H,W,cin-cin_up]; else NULL  */
+    const void*  w;         /* packed weights [cout_pad][k*k*cin] (yv3_pack_conv_weight)      */
+    const float* alpha;     /* [cout] scale; NULL means 1.0 (plain conv)                       */
+    const float* beta;      /* [cout] shift (BN) or bias (plain conv)                          */
+    const void*  residual;  /* NHWC like y, added AFTER the activation (darknet.py:53); or NULL */
+    void*        y;         /* NHWC [B,Ho,Wo,cout], Ho = (H + 2*pad - k)/stride + 1             */
+    int B, H, W;            /* input spatial size (of the full-resolution operand)             */
+    int cin;                /* total input channels (multiple of 32)                           */
+    int cin_up;             /* 0, or channels taken from the upsampled `x` (they come FIRST,
+                               as torch.cat((up, route_tail), 1) in darknet.py:162); k must be 1 */
+    int cout, cout_pad;     /* real and padded (multiple of 32) output channels                */
+    int k, stride;          /* k in {1,3}; pad = (k-1)/2 (darknet.py:34-35); stride in {1,2}   */
+    int act;                /* YV3_ACT_*                                                       */
+    int dtype;              /* YV3_F32 / YV3_BF16 (activations and packed weights)             */
+    int out_dtype;          /* dtype of y (the head convs write fp32 logits from bf16 inputs)  */
+} yv3_conv_desc;
+
+/* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */
+int yv3_conv2d(const yv3_conv_desc* desc, void* stream);
+
+/* Run `n` convolutions back to back on `stream` (one host call for a whole network plan). */
+int yv3_conv2d_sequence(const yv3_conv_desc* descs, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * YOLO head decode.  Replaces YoloLayer.forward, inference branch (yololayer.py:31-59,97-105).
+ *   bx=(sigmoid(tx)+gx)*stride  by=(sigmoid(ty)+gy)*stride
+ *   bw=exp(tw)*(aw/stride)*stride  bh likewise   conf=sigmoid(to)  cls_k=sigmoid(t_k)
+ * out row = (y*W + x)*3 + a (yololayer.py:104); columns cx,cy,w,h,conf,cls0..
+ * ------------------------------------------------------------------------------------------ */
+
+/* logits NHWC [B,H,W,3*(5+C)] with row pitch `ld_logits` floats per pixel (>= 3*(5+C)).
+ * out[b] starts at out + b*out_batch_stride (floats) and holds H*W*3 rows of (5+C) floats:
+ * pass out = base + row_offset*(5+C) to write one scale into a concatenated [B,N,5+C] tensor.
+ * anchors: 3 (w,h) pairs in input pixels (host pointer, copied by value). */
+int yv3_decode(const float* logits, int ld_logits, const float* anchors_host, float stride,
+               float* out, long long out_batch_stride, int B, int H, int W, int num_class,
+               void* stream);
+
+/* Same, reading the reference's NCHW layout [B,3*(5+C),H,W] (channel = a*(5+C)+attr,
+ * yololayer.py:42) -- the drop-in YoloLayer.forward(x) entry. */
+int yv3_decode_nchw(const float* logits_nchw, const float* anchors_host, float stride,
+                    float* out, long long out_batch_stride, int B, int H, int W, int num_class,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry helpers.  Replace boundingbox.py:25-29, utils.py:98-119, utils.py:122-146.
+ * ------------------------------------------------------------------------------------------ */
+
+/* boxes [n,4] cxcywh -> x1y1x2y2 (in place allowed: out may equal in). */
+int yv3_cxcywh_to_xyxy(const float* in, float* out, long long n, void* stream);
+
+/* out[n1,n2] = IOU(b1[i], b2[j]); boxes have `ld` floats per row (>= 4);
+ * mode 0 = x1y1x2y2, 1 = cxcywh.  No +1, no epsilon: 0/0 gives NaN like the reference. */
+int yv3_iou_matrix(const float* b1, int n1, int ld1, const float* b2, int n2, int ld2,
+                   int mode, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Post-processing.  Replaces utils.postprocessing (utils.py:226-258) with
+ * get_nms_detections (utils.py:148-202) / get_raw_detections (utils.py:204-224).
+ *
+ * Two calls so that the caller can size buffers from the candidate counts if it wants to:
+ *   1. yv3_postproc_filter : score = cls*conf, confidence filter, candidate compaction
+ *   2. yv3_postproc_nms    : order by (class asc, score desc, row asc), IOU bit masks,
+ *                            greedy scan, compaction into [B,cap,7]
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of candidate storage for up to `max_cand` candidates per image. */
+size_t yv3_postproc_cand_bytes(int B, int max_cand, int num_class);
+
+/* Bytes of scratch yv3_postproc_nms needs for up to `max_n` candidates per image. */
+size_t yv3_postproc_nms_workspace_bytes(int B, int max_n, int num_class);
+
+#define YV3_PP_EVAL 1   /* is_eval=True: every (row,k) with cls_k*conf > thr (utils.py:238)          */
+#define YV3_PP_PROB 2   /* caller guarantees 0 <= cls_k <= 1 (sigmoid outputs): rows with conf <= thr
+                           cannot pass and are skipped unread.  Same result, ~5x less traffic.      */
+
+/* dets: decoded detections [B,N,5+C] (cx,cy,w,h,conf,cls..), row pitch 5+C, NOT modified.
+ * mode: OR of YV3_PP_*.  Without YV3_PP_EVAL: one candidate per row whose max_k(cls_k*conf) > thr,
+ * class = first argmax (utils.py:242-246).
+ * cand: opaque buffer of yv3_postproc_cand_bytes(B,max_cand,C); cand_counts [B] int32 receives
+ * the number of candidates found per image (may exceed max_cand: then the excess was dropped
+ * and the caller must retry with a larger buffer). */
+int yv3_postproc_filter(const float* dets, int B, int N, int num_class, float conf_thr,
+                        int mode, void* cand, int max_cand, int* cand_counts, void* stream);
+
+/* max_n: upper bound on candidates per image that is actually processed (<= max_cand; images
+ * with more candidates are truncated).  It sizes the workspace, so a caller that has read
+ * cand_counts back can pass max(cand_counts); a sync-free caller passes max_cand.
+ * out_boxes [B,cap,7] = x1,y1,x2,y2,conf,score,cls per kept box, ordered by class ascending then
+ * score descending (utils.py:161-172,193-199); out_counts [B] = number kept (may exceed cap: rows
+ * beyond cap are dropped).  use_nms = 0 reproduces get_raw_detections: every candidate, row order.
+ * Zero-area / inverted boxes are dropped and never suppress (self-IOU not > thr, utils.py:182). */
+int yv3_postproc_nms(const float* dets, int B, int N, int num_class, float nms_thr, int use_nms,
+                     const void* cand, int max_cand, const int* cand_counts, int max_n,
+                     float* out_boxes, int cap, int* out_counts,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YV3_H */

@@ -1,0 +1,61 @@
+"""N>1 path on CPU: world_size-2 gloo run of the shard + final-box all-gather (yolo_v3_amd/dist.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from yolo_v3_amd import dist as ydist
+
+
+def test_shard_range_partitions():
+    for n, w in [(256, 8), (10, 4), (3, 8), (64, 1)]:
+        spans = [ydist.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, _, w = ydist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    B, cap = 3, 5
+    lo, hi = ydist.shard_range(B * world, rank, world)
+    boxes = torch.zeros(B, cap, 7)
+    counts = torch.zeros(B, dtype=torch.int32)
+    for i, img in enumerate(range(lo, hi)):
+        counts[i] = img % (cap + 1)
+        boxes[i, :counts[i]] = float(img) + torch.arange(int(counts[i]))[:, None] / 10.0
+    ab, ac = ydist.gather_boxes(boxes, counts)
+    ok = ab.shape == (B * world, cap, 7) and ac.tolist() == [i % (cap + 1) for i in range(B * world)]
+    for img in range(B * world):
+        n = int(ac[img])
+        ok = ok and bool((ab[img, :n, 0] == float(img) + torch.arange(n) / 10.0).all())
+    lst = ydist.boxes_to_list(ab, ac)
+    ok = ok and len(lst) == B * world and lst[0].shape == (0,) and lst[1].shape == (1, 7)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_boxes_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_single_process_is_identity():
+    b, c = torch.zeros(2, 4, 7), torch.tensor([1, 0], dtype=torch.int32)
+    ab, ac = ydist.gather_boxes(b, c)
+    assert ab is b and ac is c
+    assert ydist.boxes_to_list(torch.zeros(2, 4, 7), torch.zeros(2, dtype=torch.int32)) == []

