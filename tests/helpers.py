@@ -20,6 +20,12 @@ def assert_close_rel(a, ref, tol=TOL, what=""):
 def match_boxes(got, exp, tol=TOL):
     """Order-insensitive comparison of two [n,7] box lists (x1,y1,x2,y2,conf,score,cls): same count,
     same class multiset, and a one-to-one pairing within each class with every column within tol.
+
+    Normalisation: conf/score by max(1,|ref|) (= 1); the four corner coordinates by the box's
+    largest coordinate magnitude, max(1, |x1|,|y1|,|x2|,|y2|).  Corners are x = cx -/+ w/2
+    (boundingbox.py:25-29): when cx ~ w/2 the subtraction cancels, so the achievable error of a
+    corner is tol * the magnitude of its OPERANDS, not of the (possibly tiny) difference.  The
+    un-cancelled quantities (cx,cy,w,h,conf,cls) are checked elementwise by assert_close_rel.
     Returns the worst normalised error."""
     got, exp = torch.as_tensor(got).double(), torch.as_tensor(exp).double()
     assert got.numel() == 0 or got.dim() == 2
@@ -30,7 +36,9 @@ def match_boxes(got, exp, tol=TOL):
     for c in exp[:, 6].unique():
         g, e = got[got[:, 6] == c], exp[exp[:, 6] == c]
         assert len(g) == len(e), "class %d: got %d boxes, expected %d" % (int(c), len(g), len(e))
-        d = ((g[:, None, :6] - e[None, :, :6]).abs() / e[None, :, :6].abs().clamp(min=1.0)).amax(-1)   # [ng, ne]
+        scale = torch.ones_like(e[:, :6])
+        scale[:, :4] = e[:, :4].abs().amax(1, keepdim=True).clamp(min=1.0)
+        d = ((g[:, None, :6] - e[None, :, :6]).abs() / scale[None]).amax(-1)                            # [ng, ne]
         used = set()
         for j in range(len(e)):
             i = int(d[:, j].argmin())

@@ -245,7 +245,7 @@ def test_head_conv_255_and_asymmetric_layout():
     head = torch.nn.Conv2d(64, 255, 1)
     with torch.no_grad():
         head.weight.copy_(torch.arange(255 * 64).float().view(255, 64, 1, 1) % 17 - 8.0)
-        head.bias.copy_(torch.arange(255).float() / 10)
+        head.bias.copy_(torch.arange(255).float() / 8)
     x = (torch.arange(2 * 64 * 5 * 7).float().view(2, 64, 5, 7) % 13) - 6.0
     ref = F.conv2d(x.double(), head.weight.double(), head.bias.double())
     grp = PreDetectionConvGroup(64, 32, num_conv=0, numClass=80)

@@ -65,6 +65,12 @@ struct CandView {
 };
 __host__ __device__ inline size_t cand_keys_bytes(int B, int max_cand) { return ((size_t)B * max_cand * 8 + 255) & ~(size_t)255; }
 
+__global__ void zero_kernel(int* a, int na, int* b, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = 0;
+    if (i < nb) b[i] = 0;
+}
+
 template <bool EVAL>
 __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ dets, int N, int C, float thr, bool prob,
                                                      u64* keys, int* segcnt, int max_cand, int* counts) {
@@ -366,10 +372,11 @@ extern "C" int yv3_postproc_filter(const float* dets, int B, int N, int num_clas
     hipStream_t s = (hipStream_t)stream;
     u64* keys = (u64*)cand;
     int* segcnt = (int*)((char*)cand + cand_keys_bytes(B, max_cand));
-    hipError_t e = hipMemsetAsync(cand_counts, 0, (size_t)B * 4, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(segcnt, 0, (size_t)B * num_class * 4, s);
-    if (e != hipSuccess) return (int)e;
+    // counters are cleared by a kernel, not hipMemsetAsync: memset nodes captured into a hipGraph
+    // were observed to write garbage from the second replay on (ROCm 7.2, gfx950)
+    hipLaunchKernelGGL(zero_kernel, dim3(yv3_ceil_div((long long)B * num_class, 256)), dim3(256), 0, s,
+                       cand_counts, B, segcnt, B * num_class);
+    YV3_CHECK_LAUNCH();
     const dim3 grid((unsigned)yv3_ceil_div(N, 256), (unsigned)B);
     const bool prob = (mode & YV3_PP_PROB) != 0 && conf_thr >= 0.f;
     if (mode & YV3_PP_EVAL) hipLaunchKernelGGL(filter_kernel<true>, grid, dim3(256), 0, s, dets, N, num_class, conf_thr, prob, keys, segcnt, max_cand, cand_counts);

@@ -84,6 +84,12 @@ def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=F
     if num_classes is not None and num_classes != net.numClass:
         raise _ffi.Yv3Error("num_classes=%d does not match net.numClass=%d" % (num_classes, net.numClass))
     _ffi.require_cuda(imgs, "imgs")
+    if is_eval:
+        # multi-label mode can produce up to N*C candidates per image: size the buffers from the
+        # actual counts (one extra host sync) instead of the worst case
+        from .utils import postprocessing
+        with torch.no_grad():
+            return postprocessing(net.forward_cat(imgs), net.numClass, obj_conf_thr, nms_thr, True, use_nms)
     key = (tuple(imgs.shape), imgs.device, float(obj_conf_thr), float(nms_thr), bool(is_eval), bool(use_nms))
     cache = net.__dict__.setdefault("_detectors", {})
     det = cache.get(key)
