@@ -32,11 +32,23 @@ import torch.distributed as dist   # noqa: E402
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(stream, size, n_img=8):
     """Oracle (CPU restatement of the reference path) on the host cores: forward + post-processing."""
     from oracle import oracle_cpu as oc
     from yolo_v3_amd import synth
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd, _ = oc.state_dict_from_stream(stream)
     x = torch.from_numpy(synth.images(n_img, size, 1))

@@ -1,0 +1,42 @@
+"""Micro-benchmark of single conv layers through the C-ABI (for kernel tuning)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_v3_amd import _ffi, arch, engine
+from yolo_v3_amd.darknet import conv_bn_relu
+
+LAYERS = {  # name: cin, cout, k, stride, H (input), res
+    "c52": (128, 256, 3, 1, 52, True), "c26": (256, 512, 3, 1, 26, True), "c13": (512, 1024, 3, 1, 13, True),
+    "c104": (64, 128, 3, 1, 104, True), "c208": (32, 64, 3, 1, 208, True), "d208": (32, 64, 3, 2, 416, False),
+    "p26": (512, 256, 1, 1, 26, False), "p52": (256, 128, 1, 1, 52, False), "p13": (1024, 512, 1, 1, 13, False),
+    "p104": (128, 64, 1, 1, 104, False), "p208": (64, 32, 1, 1, 208, False),
+}
+B = int(os.environ.get("BB", "64"))
+iters = int(os.environ.get("ITERS", "10"))
+dt = _ffi.BF16 if os.environ.get("DT", "f32") == "bf16" else _ffi.F32
+tdt = torch.bfloat16 if dt == _ffi.BF16 else torch.float32
+names = sys.argv[1:] or list(LAYERS)
+torch.cuda.set_device(0)
+lib = _ffi.lib()
+for name in names:
+    cin, cout, k, s, H, res = LAYERS[name]
+    m = conv_bn_relu(cin, cout, k, s).cuda().eval()
+    sp = m._spec()
+    pc = engine.pack_conv(m, sp, dt)
+    x = (torch.rand(B, H, H, cin, device="cuda") - 0.5).to(tdt)
+    ho, wo = engine.out_hw(H, H, k, s)
+    y = torch.empty(B, ho, wo, cout, device="cuda", dtype=tdt)
+    r = (torch.rand(B, ho, wo, cout, device="cuda") - 0.5).to(tdt) if res else None
+    d = engine.make_desc(pc, x, y, B, H, H, r, dtype=dt)
+    st = _ffi.stream_ptr()
+    for _ in range(3):
+        _ffi.check(lib.yv3_conv2d(d, st))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        _ffi.check(lib.yv3_conv2d(d, st))
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * B * ho * wo * cout * cin * k * k
+    print("%-5s B=%d %dx%d %d->%d k%d s%d : %.3f ms  %.1f TF" % (name, B, H, H, cin, cout, k, s, ms, fl / ms / 1e9)); sys.stdout.flush()
