@@ -33,8 +33,12 @@ extern "C" {
 #define YV3_EWORKSPACE (-3)      /* workspace too small                                     */
 #define YV3_EDTYPE   (-4)        /* unknown dtype code                                      */
 
-#define YV3_F32  0
-#define YV3_BF16 1
+/* Tensor / math modes.  "Plane" tensors are NP bf16 planes [NP][B,H,W,C] (plane stride B*H*W*C).   */
+#define YV3_F32  0               /* fp32 NHWC tensors, exact fp32 MFMA (v_mfma_f32_32x32x2_f32)          */
+#define YV3_BF16 1               /* 1 bf16 plane, bf16 MFMA, fp32 accumulate                             */
+#define YV3_F32_BF16X3 2         /* 3 bf16 planes = exact split v = p0+p1+p2 of an fp32 value; every fp32
+                                    product is evaluated as its 6 leading bf16 partial products with fp32
+                                    accumulation: fp32-class error at ~2.7x the fp32-MFMA rate            */
 
 #define YV3_ACT_LINEAR 0
 #define YV3_ACT_LEAKY  1         /* LeakyReLU(0.1), reference darknet.py:41 */
@@ -47,7 +51,9 @@ const char* yv3_error_string(int code);
  * path; it turns the parameters WeightManager loads (darknet.py:279-290) into kernel layout.
  * ------------------------------------------------------------------------------------------ */
 
-/* OIHW fp32 [cout][cin][k][k]  ->  K-major [cout_pad][k][k][cin] in `dtype`; rows >= cout are 0. */
+/* OIHW fp32 [cout][cin][k][k]  ->  kernel layout for `dtype`; rows >= cout are 0.
+ * YV3_F32: K-major [cout_pad][k][k][cin] fp32.  YV3_BF16 / YV3_F32_BF16X3: NP = 1 / 3 bf16 planes
+ * pre-arranged tile by tile in the kernel's LDS image order; needs NP * cout_pad*k*k*cin * 2 bytes. */
 int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin, int k,
                          int cout_pad, int dtype, void* stream);
 
@@ -56,6 +62,11 @@ int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin,
 int yv3_fold_bn(const float* gamma, const float* bias, const float* mean, const float* var,
                 float eps, float* alpha, float* beta, int channels, void* stream);
 
+/* fp32 [n] <-> NP bf16 planes [NP][n] (np = 1 or 3; 3 is an exact, loss-free split). Layout
+ * conversion helpers for callers that hold fp32 tensors; not used inside the fused network plan. */
+int yv3_split_planes(const float* in, void* out, long long n, int np, void* stream);
+int yv3_merge_planes(const void* in, float* out, long long n, int np, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolutions.  Replace conv_bn_relu.forward (darknet.py:43-44), res_layer.forward
  * (darknet.py:52-53), the plain head Conv2d (darknet.py:118) and UpsampleGroup's
@@ -63,7 +74,8 @@ int yv3_fold_bn(const float* gamma, const float* bias, const float* mean, const 
  * ------------------------------------------------------------------------------------------ */
 
 /* First layer, feature.mlist.0: 3 -> 32 channels, 3x3, stride 1, pad 1, + BN + leaky.
- * x is the caller's NCHW fp32 image batch [B,3,H,W] (values in [0,1]); y is NHWC [B,H,W,32].
+ * x is the caller's NCHW fp32 image batch [B,3,H,W] (values in [0,1]); y is NHWC [B,H,W,32] in
+ * out_dtype (fp32, or 1 / 3 bf16 planes).
  * w_tap_major is the OIHW weight permuted to [cin][kh][kw][cout] = [27][32] fp32;
  * alpha/beta from yv3_fold_bn. */
 int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
@@ -85,8 +97,8 @@ typedef struct yv3_conv_desc {
     int cout, cout_pad;     /* real and padded (multiple of 32) output channels                */
     int k, stride;          /* k in {1,3}; pad = (k-1)/2 (darknet.py:34-35); stride in {1,2}   */
     int act;                /* YV3_ACT_*                                                       */
-    int dtype;              /* YV3_F32 / YV3_BF16 (activations and packed weights)             */
-    int out_dtype;          /* dtype of y (the head convs write fp32 logits from bf16 inputs)  */
+    int dtype;              /* YV3_F32 / YV3_BF16 / YV3_F32_BF16X3: format of x, x2, residual, w */
+    int out_dtype;          /* format of y: == dtype, or YV3_F32 (head convs write fp32 logits) */
 } yv3_conv_desc;
 
 /* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */

@@ -91,20 +91,46 @@ def test_decisions_exact_on_identical_detections(net):
         assert torch.equal(r, e)
 
 
-def test_conv_trunk_vs_oracle_layerwise(net, sw1_stream):
-    """Per-layer bring-up check: every conv output of the plan vs the oracle's tap (B=1, 416)."""
+@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3])
+def test_conv_trunk_vs_oracle_layerwise(net, sw1_stream, mode):
+    """Per-layer bring-up check: every conv output of the plan vs the oracle's tap (B=1, 416), in the
+    exact-fp32 MFMA mode and in the bf16x3-split mode (same tolerance: both are fp32-class arithmetic)."""
+    from yolo_v3_amd import engine
     x = torch.from_numpy(synth.images(1, 416, 11))
     sd, _ = oc.state_dict_from_stream(sw1_stream)
     taps = []
     with torch.no_grad():
         oc.head_logits(sd, x, taps)
-        eng = net.engine()
+        eng = net.engine(mode)
         _, plan = eng.forward(x.cuda())
     torch.cuda.synchronize()
     assert len(taps) == 75
+    worst = 0.0
     for name, ref in taps:
-        got = plan.layer_out[name].permute(0, 3, 1, 2).float().cpu()
-        assert_close_rel(got, ref, TOL, name)
+        got = engine.from_planes(plan.layer_out[name], mode).permute(0, 3, 1, 2).float().cpu()
+        worst = max(worst, assert_close_rel(got, ref, TOL, name))
+    print("mode %d: worst layer error %.3g" % (mode, worst))
+
+
+@pytest.mark.parametrize("name", ["dog416", "u416", "u608"])
+def test_split_mode_boxes_vs_reference_golden(golden_dir, net, name):
+    """The throughput mode (YV3_F32_BF16X3) against the reference's golden detections and boxes, at the
+    same 1e-4 tolerance as the exact-fp32 mode."""
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    x = _input(g, name).cuda()
+    with torch.no_grad():
+        dets = net.forward_cat(x, dtype=_ffi.F32X3)
+    rows = g[name + "_rows"]
+    err = assert_close_rel(dets[:, rows].cpu(), g[name + "_dets_rows"], TOL, name + " detections (split mode)")
+    res = postprocessing(dets, 80, 0.5, 0.4)
+    assert len(res) == int(g[name + "_nres"][0])
+    worst = 0.0
+    for i, r in enumerate(res):
+        worst = max(worst, match_boxes(r, g["%s_boxes%d" % (name, i)], TOL))
+    det = Detector(net, x.shape[0], x.shape[2], x.shape[3], dtype=_ffi.F32X3)
+    for r, f in zip(res, det(x)):
+        assert torch.equal(r, f)
+    print("%s split mode: max detection err %.3g, max box err %.3g" % (name, err, worst))
 
 
 def test_full_size_properties(net):

@@ -182,6 +182,20 @@ def _ref_cbr(m, x):
     return F.leaky_relu(y, 0.1)
 
 
+def _run_mode(m, x_nchw, mode, residual_nchw=None):
+    """conv_bn_relu `m` (already on the GPU) on NCHW fp32 input through the C-ABI in math mode `mode`."""
+    sp = m._spec()
+    pc = engine.pack_conv(m, sp, mode)
+    B, _, H, W = x_nchw.shape
+    x = engine.to_planes(x_nchw.cuda().permute(0, 2, 3, 1).contiguous(), mode)
+    ho, wo = engine.out_hw(H, W, sp.k, sp.stride)
+    y = engine.alloc_act(B, ho, wo, sp.cout, mode, "cuda")
+    r = engine.to_planes(residual_nchw.cuda().permute(0, 2, 3, 1).contiguous(), mode) if residual_nchw is not None else None
+    d = engine.make_desc(pc, x, y, B, H, W, r, dtype=mode)
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    return engine.from_planes(y, mode).permute(0, 3, 1, 2).cpu()
+
+
 CONV_CASES = [
     # cin, cout, k, stride, B, H, W    (covers every tile config, halo handling, M tails, stride 2)
     (3, 32, 3, 1, 2, 40, 56),
@@ -209,6 +223,30 @@ def test_conv_bn_relu_vs_fp64(cin, cout, k, s, B, H, W):
     out = m.cuda()(x.cuda()).cpu()
     assert out.shape == ref.shape
     assert_close_rel(out, ref, 2e-5, "conv %s" % ((cin, cout, k, s),))
+
+
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W", [c for c in CONV_CASES if c[0] != 3] + [(64, 128, 3, 1, 70, 26, 26), (256, 256, 1, 1, 40, 26, 26)])
+def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W):
+    """Same layers in YV3_F32_BF16X3 mode (bf16-plane tensors, 6 bf16 MFMAs per fp32 product, fp32
+    accumulate).  The split is exact and the dropped partial products are <= 2^-26 of each product, so
+    the SAME fp32 round-off tolerance as the exact-fp32 kernel applies: 2e-5 * max(1,|ref|)."""
+    m = _rand_cbr(cin, cout, k, s, seed=cin + cout + k)
+    x = torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(1)) * 2 - 0.5
+    ho, wo = engine.out_hw(H, W, k, s)
+    res = torch.rand(B, cout, ho, wo, generator=torch.Generator().manual_seed(2)) - 0.5
+    ref = _ref_cbr(m, x) + res.double()
+    out = _run_mode(m.cuda(), x, _ffi.F32X3, res)
+    assert out.shape == ref.shape
+    assert_close_rel(out, ref, 2e-5, "split conv %s" % ((cin, cout, k, s),))
+
+
+def test_plane_split_is_exact():
+    """fp32 -> 3 bf16 planes -> fp32 is the identity (8+8+8 mantissa bits), including tiny/huge values."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat((torch.randn(100000, generator=g), torch.randn(1000, generator=g) * 1e-30,
+                   torch.randn(1000, generator=g) * 1e30, torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38]))).cuda()
+    back = engine.from_planes(engine.to_planes(x.view(1, 1, 1, -1), _ffi.F32X3), _ffi.F32X3).view(-1)
+    assert torch.equal(back, x)
 
 
 def test_residual_block_and_upsample_concat():

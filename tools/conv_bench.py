@@ -13,8 +13,8 @@ LAYERS = {  # name: cin, cout, k, stride, H (input), res
 }
 B = int(os.environ.get("BB", "64"))
 iters = int(os.environ.get("ITERS", "10"))
-dt = _ffi.BF16 if os.environ.get("DT", "f32") == "bf16" else _ffi.F32
-tdt = torch.bfloat16 if dt == _ffi.BF16 else torch.float32
+dt = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3}[os.environ.get("DT", "f32")]
+tdt = torch.float32
 names = sys.argv[1:] or list(LAYERS)
 torch.cuda.set_device(0)
 lib = _ffi.lib()
@@ -23,10 +23,12 @@ for name in names:
     m = conv_bn_relu(cin, cout, k, s).cuda().eval()
     sp = m._spec()
     pc = engine.pack_conv(m, sp, dt)
-    x = (torch.rand(B, H, H, cin, device="cuda") - 0.5).to(tdt)
+    xf = torch.rand(B, H, H, cin, device="cuda") - 0.5
     ho, wo = engine.out_hw(H, H, k, s)
-    y = torch.empty(B, ho, wo, cout, device="cuda", dtype=tdt)
-    r = (torch.rand(B, ho, wo, cout, device="cuda") - 0.5).to(tdt) if res else None
+    rf = (torch.rand(B, ho, wo, cout, device="cuda") - 0.5) if res else None
+    x = engine.to_planes(xf, dt)
+    r = engine.to_planes(rf, dt) if res else None
+    y = engine.alloc_act(B, ho, wo, cout, dt, "cuda")
     d = engine.make_desc(pc, x, y, B, H, H, r, dtype=dt)
     st = _ffi.stream_ptr()
     for _ in range(3):
@@ -39,4 +41,12 @@ for name in names:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * ho * wo * cout * cin * k * k
-    print("%-5s B=%d %dx%d %d->%d k%d s%d : %.3f ms  %.1f TF" % (name, B, H, H, cin, cout, k, s, ms, fl / ms / 1e9)); sys.stdout.flush()
+    extra = ""
+    if dt != _ffi.F32 and os.environ.get("CHECK", "1") == "1":
+        pc0 = engine.pack_conv(m, sp, _ffi.F32)
+        y0 = torch.empty(B, ho, wo, cout, device="cuda")
+        d0 = engine.make_desc(pc0, engine.from_planes(x, dt), y0, B, H, H, engine.from_planes(r, dt) if res else None, dtype=_ffi.F32)
+        _ffi.check(lib.yv3_conv2d(d0, st)); torch.cuda.synchronize()
+        err = ((engine.from_planes(y, dt) - y0).abs() / y0.abs().clamp(min=1.0)).max().item()
+        extra = "  max|d| vs exact-fp32 kernel %.3g" % err
+    print("%-5s B=%d %dx%d %d->%d k%d s%d : %.3f ms  %.1f TF" % (name, B, H, H, cin, cout, k, s, ms, fl / ms / 1e9) + extra); sys.stdout.flush()

@@ -8,9 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyv3.so")
+LIB_PATH = os.environ.get("YV3_LIB") or os.path.join(_HERE, "libyv3.so")     # YV3_LIB: kernel-tuning builds only
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 ACT_LINEAR, ACT_LEAKY = 0, 1
 PP_EVAL, PP_PROB = 1, 2
 
@@ -32,6 +32,8 @@ _SIGNATURES = {
     "yv3_error_string": (ctypes.c_char_p, [c_int]),
     "yv3_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_fold_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "yv3_split_planes": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p]),
+    "yv3_merge_planes": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p]),
     "yv3_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "yv3_conv2d_sequence": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),

@@ -2,7 +2,7 @@
 #include "yv3_common.h"
 
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s);
-int yv3_conv2d_bf16(const yv3_conv_desc* d, hipStream_t s);
+int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s);
 
 extern "C" int yv3_version(void) { return YV3_VERSION; }
 
@@ -38,7 +38,11 @@ extern "C" int yv3_conv2d(const yv3_conv_desc* d, void* stream) {
         if (d->out_dtype != YV3_F32) return YV3_EDTYPE;
         return yv3_conv2d_f32(d, (hipStream_t)stream);
     }
-    if (d->dtype == YV3_BF16) return yv3_conv2d_bf16(d, (hipStream_t)stream);
+    if (d->dtype == YV3_F32_BF16X3 || d->dtype == YV3_BF16) {
+        if (d->out_dtype != YV3_F32 && d->out_dtype != d->dtype) return YV3_EDTYPE;
+        if (d->cin % 32) return YV3_ESHAPE;
+        return yv3_conv2d_planes(d, d->dtype == YV3_BF16 ? 1 : 3, (hipStream_t)stream);
+    }
     return YV3_EDTYPE;
 }
 

@@ -12,10 +12,11 @@
 
 namespace {
 
-template <typename OutT>
+// NP = 0: fp32 NHWC output; NP = 1 / 3: bf16 planes [NP][B,H,W,32] (3 = exact split of the fp32 value)
+template <int NP>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                    const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                   OutT* __restrict__ y, int H, int W) {
+                                                   void* __restrict__ yv, int H, int W, long long plane_stride) {
     __shared__ float tile[256 * 33];
     const int b = blockIdx.y;
     const int HW = H * W;
@@ -56,13 +57,27 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
     __syncthreads();
     const size_t obase = ((size_t)b * HW + pix0) * 32;
     const int nvalid = min(256, HW - pix0) * 32;
+    if constexpr (NP == 0) {
+        float* y = (float*)yv;
 #pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-        const int e = i * 256 + threadIdx.x;
-        if (e < nvalid) {
-            const float v = tile[(e >> 5) * 33 + (e & 31)];
-            if constexpr (sizeof(OutT) == 4) y[obase + e] = v;
-            else y[obase + e] = yv3_f2bf(v);
+        for (int i = 0; i < 32; ++i) {
+            const int e = i * 256 + threadIdx.x;
+            if (e < nvalid) y[obase + e] = tile[(e >> 5) * 33 + (e & 31)];
+        }
+    } else {
+        u16* y = (u16*)yv;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int e = 2 * (i * 256 + threadIdx.x);            // two consecutive channels of one pixel
+            if (e < nvalid) {
+                float v0 = tile[(e >> 5) * 33 + (e & 31)], v1 = tile[(e >> 5) * 33 + (e & 31) + 1];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const u16 h0 = yv3_f2bf(v0), h1 = yv3_f2bf(v1);
+                    *reinterpret_cast<unsigned*>(y + pl * plane_stride + obase + e) = (unsigned)h0 | ((unsigned)h1 << 16);
+                    v0 -= yv3_bf2f(h0); v1 -= yv3_bf2f(h1);
+                }
+            }
         }
     }
 }
@@ -75,10 +90,13 @@ extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const fl
     if (!x_nchw || !w_tap_major || !alpha || !beta || !y_nhwc || B <= 0 || H <= 0 || W <= 0) return YV3_EINVAL;
     const dim3 grid((unsigned)yv3_ceil_div((long long)H * W, 256), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
+    const long long ps = (long long)B * H * W * 32;
     if (out_dtype == YV3_F32)
-        hipLaunchKernelGGL(conv0_kernel<float>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, (float*)y_nhwc, H, W);
+        hipLaunchKernelGGL(conv0_kernel<0>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else if (out_dtype == YV3_BF16)
-        hipLaunchKernelGGL(conv0_kernel<u16>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, (u16*)y_nhwc, H, W);
+        hipLaunchKernelGGL(conv0_kernel<1>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
+    else if (out_dtype == YV3_F32_BF16X3)
+        hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else
         return YV3_EDTYPE;
     YV3_CHECK_LAUNCH();

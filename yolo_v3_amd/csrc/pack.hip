@@ -3,11 +3,12 @@
 //  darknet.py:279-290; these kernels turn them into the layout the conv kernels consume.)
 #include "yv3_common.h"
 
+int yv3_pack_weight_planes(const float* w_oihw, void* w_packed, int cout, int cin, int k, int cout_pad, int np, hipStream_t s);
+
 namespace {
 
 template <typename T> __device__ inline T cvt(float v);
 template <> __device__ inline float cvt<float>(float v) { return v; }
-template <> __device__ inline u16 cvt<u16>(float v) { return yv3_f2bf(v); }
 
 // out[n][kh][kw][c] = in[n][c][kh][kw]; rows n >= cout are zero-filled.
 template <typename T>
@@ -43,10 +44,10 @@ extern "C" int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cou
     const long long total = (long long)cout_pad * k * k * cin;
     const int blocks = yv3_ceil_div(total, 256);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == YV3_F32_BF16X3) return yv3_pack_weight_planes(w_oihw, w_packed, cout, cin, k, cout_pad, 3, s);
+    if (dtype == YV3_BF16) return yv3_pack_weight_planes(w_oihw, w_packed, cout, cin, k, cout_pad, 1, s);
     if (dtype == YV3_F32)
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_packed, cout, cin, k, total);
-    else if (dtype == YV3_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<u16>, dim3(blocks), dim3(256), 0, s, w_oihw, (u16*)w_packed, cout, cin, k, total);
     else
         return YV3_EDTYPE;
     YV3_CHECK_LAUNCH();

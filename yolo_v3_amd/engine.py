@@ -18,9 +18,38 @@ import ctypes
 import torch
 
 from . import _ffi, arch
-from ._ffi import ConvDesc, F32, BF16, ACT_LEAKY, ACT_LINEAR
+from ._ffi import ConvDesc, F32, BF16, F32X3, ACT_LEAKY, ACT_LINEAR
 
-_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F32X3: torch.bfloat16}    # element type of activation storage
+PLANES = {F32: 0, BF16: 1, F32X3: 3}       # 0: plain fp32 NHWC tensor; n > 0: n bf16 planes [n][B,H,W,C]
+
+
+def alloc_act(B, h, w, c, dtype, device):
+    """Activation buffer in the layout of `dtype` (include/yv3.h): fp32 NHWC, or NP bf16 planes."""
+    np_ = PLANES[dtype]
+    shape = (B, h, w, c) if np_ == 0 else (np_, B, h, w, c)
+    return torch.empty(shape, device=device, dtype=_TORCH_DTYPE[dtype])
+
+
+def to_planes(x_nhwc_f32, dtype):
+    """fp32 NHWC tensor -> the activation layout of `dtype` (exact for F32X3)."""
+    np_ = PLANES[dtype]
+    if np_ == 0:
+        return x_nhwc_f32.float().contiguous()
+    x = x_nhwc_f32.float().contiguous()
+    out = torch.empty((np_,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16)
+    _ffi.check(_ffi.lib().yv3_split_planes(x.data_ptr(), out.data_ptr(), x.numel(), np_, _ffi.stream_ptr()), "yv3_split_planes")
+    return out
+
+
+def from_planes(t, dtype):
+    """Activation buffer of `dtype` -> fp32 NHWC tensor."""
+    np_ = PLANES[dtype]
+    if np_ == 0 or t.dtype == torch.float32:
+        return t
+    out = torch.empty(tuple(t.shape[1:]), device=t.device, dtype=torch.float32)
+    _ffi.check(_ffi.lib().yv3_merge_planes(t.data_ptr(), out.data_ptr(), out.numel(), np_, _ffi.stream_ptr()), "yv3_merge_planes")
+    return out
 
 
 def _ptr(t):
@@ -64,7 +93,8 @@ def pack_conv(module, spec, dtype):
         # first layer: direct-conv kernel wants [cin][kh][kw][cout] fp32
         return PackedConv(spec, w32.permute(1, 2, 3, 0).contiguous(), alpha, beta, spec.cout)
     cout_pad = (spec.cout + 31) // 32 * 32
-    wp = torch.empty(cout_pad * spec.k * spec.k * spec.cin, device=dev, dtype=_TORCH_DTYPE[dtype])
+    nw = cout_pad * spec.k * spec.k * spec.cin
+    wp = torch.empty(max(1, PLANES[dtype]) * nw, device=dev, dtype=_TORCH_DTYPE[dtype])
     _ffi.check(lib.yv3_pack_conv_weight(w32.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, spec.k,
                                         cout_pad, dtype, s), "yv3_pack_conv_weight")
     return PackedConv(spec, wp, alpha, beta, cout_pad)
@@ -98,7 +128,6 @@ class Plan:
             raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
         self.B, self.H, self.W = B, H, W
         dev, dt = engine.device, engine.dtype
-        tdt = _TORCH_DTYPE[dt]
         packed = engine.packed
         nc = engine.num_class
         attrib = 5 + nc
@@ -106,15 +135,15 @@ class Plan:
         descs = []
         self.layer_out = {}  # conv name -> (buffer, (h, w, c)) for bring-up / per-layer parity tests
 
-        def buf(h, w, c, dtype=tdt):
-            t = torch.empty((B, h, w, c), device=dev, dtype=dtype)
+        def buf(h, w, c, dtype=dt):
+            t = alloc_act(B, h, w, c, dtype, dev)
             keep.append(t)
             return t
 
         def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
             pc = packed[i]
             ho, wo = out_hw(h, w, pc.spec.k, pc.spec.stride)
-            y = buf(ho, wo, pc.spec.cout, _TORCH_DTYPE[dt if out_dtype is None else out_dtype])
+            y = buf(ho, wo, pc.spec.cout, dt if out_dtype is None else out_dtype)
             descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype))
             self.layer_out[pc.spec.name] = y
             return y, ho, wo
@@ -242,7 +271,7 @@ class Engine:
         bstride = plan.N * plan.attrib
         for anc, stride, row0, lg, hh, ww in plan.decode_args:
             out_ptr = dets.data_ptr() + row0 * plan.attrib * 4
-            _ffi.check(lib.yv3_decode(lg.data_ptr(), lg.shape[3], anc, stride, out_ptr, bstride,
+            _ffi.check(lib.yv3_decode(lg.data_ptr(), lg.shape[-1], anc, stride, out_ptr, bstride,
                                       plan.B, hh, ww, self.num_class, s), "yv3_decode")
 
     def prepare_input(self, x):
