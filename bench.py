@@ -203,6 +203,18 @@ def main():
                          "flop_per_launch_avg": flops_igemm / n_desc,
                          "end_to_end_frac": round(flops_all / (ms_per_step * 1e-3) / 1e12 / peak, 4)},
         }
+        # HBM traffic of the dominant kernel family comes from separate rocprofv3 --pmc passes (FETCH_SIZE and
+        # WRITE_SIZE cannot be sampled from inside this process); the committed summary for this exact
+        # workload is attached when present (tools/traffic_summary.py, profiles/*_traffic_*.json).
+        tpath = os.path.join(REPO, "profiles", "r01b_traffic_%s_%d_bs%d.json" % (args.dtype, args.size, B))
+        if os.path.exists(tpath):
+            fam = json.load(open(tpath)).get(KERNEL_NAME[args.dtype].split("<")[0])
+            if fam:
+                out["roofline"]["traffic"] = round(fam["hbm_bytes_per_step_fetch_x2"] / n_desc)
+                out["roofline"]["traffic_note"] = ("HBM bytes per launch (avg of %d launches/step) = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                                                   "from rocprofv3 --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 "
+                                                   "calibration in MI355X_MICROARCH.md (confirmed here on decode_kernel); source %s"
+                                                   % (n_desc, os.path.basename(tpath)))
         if args.dtype == "f32x3":
             out["roofline"]["note"] = ("achieved = algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per "
                                        "fp32 product, so frac = bf16 matrix-pipe utilisation (%.0f TFLOP/s executed)" % (6 * achieved))
