@@ -133,6 +133,33 @@ def test_split_mode_boxes_vs_reference_golden(golden_dir, net, name):
     print("%s split mode: max detection err %.3g, max box err %.3g" % (name, err, worst))
 
 
+def test_bf16_mode_config3_shape(net):
+    """BASELINE configs[2] shape (608x608, bf16 convs / fp32 decode), B=4.  bf16 is the reduced-precision
+    throughput mode, outside the 1e-4 bar: detections must stay close to the exact-fp32 mode on average
+    (mean normalised error < 5e-3) and most boxes must survive with matching class and IOU > 0.9."""
+    x = torch.from_numpy(synth.images(4, 608, 77)).cuda()
+    with torch.no_grad():
+        d32 = net.forward_cat(x, dtype=_ffi.F32)
+        dbf = net.forward_cat(x, dtype=_ffi.BF16)
+    assert dbf.shape == (4, 22743, 85)
+    e = (dbf - d32).abs() / d32.abs().clamp(min=1.0)
+    assert float(e.mean()) < 5e-3, float(e.mean())
+    r32, rbf = postprocessing(d32, 80, 0.5, 0.4), postprocessing(dbf, 80, 0.5, 0.4)
+    n32, matched = 0, 0
+    for a, b in zip(r32, rbf):
+        n32 += len(a)
+        if len(a) and len(b):
+            iou = bbox_iou_gpu(a[:, :4], b[:, :4])
+            same = a[:, 6][:, None] == b[:, 6][None, :]
+            matched += int(((iou > 0.9) & same).any(1).sum())
+    assert n32 > 20 and matched >= 0.6 * n32, (n32, matched)     # bf16 noise moves boxes whose w,h = exp(t)*anchor are huge
+
+
+def bbox_iou_gpu(a, b):
+    from yolo_v3_amd import bbox_iou
+    return bbox_iou(a.cuda(), b.cuda()).cpu()
+
+
 def test_full_size_properties(net):
     """BASELINE configs[1] size (32 x 416 x 416): batch independence (duplicated / permuted images give
     identical boxes bit for bit) and agreement of eager vs HIP-graph replay."""

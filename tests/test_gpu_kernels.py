@@ -240,6 +240,19 @@ def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W):
     assert_close_rel(out, ref, 2e-5, "split conv %s" % ((cin, cout, k, s),))
 
 
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(32, 64, 3, 2, 2, 40, 56), (128, 256, 3, 1, 5, 13, 13), (512, 256, 1, 1, 33, 13, 13),
+                                                 (256, 128, 1, 1, 64, 26, 26), (512, 1024, 3, 1, 24, 13, 13)])
+def test_conv_bf16_mode_vs_fp64(cin, cout, k, s, B, H, W):
+    """YV3_BF16 (BASELINE config 3: bf16 convs): bf16 tensors + weights, fp32 accumulate and epilogue.
+    NOT a 1e-4 mode: operands carry 2^-9 relative rounding, so the tolerance is 2e-2 * max(1,|ref|)
+    against an fp64 reference fed the same bf16-rounded input."""
+    m = _rand_cbr(cin, cout, k, s, seed=cin + cout + k)
+    x = (torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(1)) * 2 - 0.5).bfloat16().float()
+    ref = _ref_cbr(m, x)
+    out = _run_mode(m.cuda(), x, _ffi.BF16)
+    assert_close_rel(out, ref, 2e-2, "bf16 conv %s" % ((cin, cout, k, s),))
+
+
 def test_plane_split_is_exact():
     """fp32 -> 3 bf16 planes -> fp32 is the identity (8+8+8 mantissa bits), including tiny/huge values."""
     g = torch.Generator().manual_seed(5)

@@ -346,7 +346,7 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, hipStream
     const dim3 grid((unsigned)(mtiles * p.ntiles));
     const dim3 block(64 * WM * WN);
     const size_t pipe = (size_t)NSTAGE * NP * (BM + BN) * ROWB;
-    const size_t epi = (size_t)BM * (BN / WN + 4) * 4;        // WM*WN waves x (BM/WM) rows x (BN/WN + 4) floats
+    const size_t epi = (size_t)WN * BM * (BN / WN + 4) * 4;   // WM*WN waves x (BM/WM) rows x (BN/WN + 4) floats
     const size_t lds = pipe > epi ? pipe : epi;
 #define YV3_LAUNCH(K3_, DUAL_, OF_) \
     hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_>), grid, block, lds, s, p)
