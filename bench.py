@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--nms", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", default="sw1", choices=["sw1", "dense"],
+                    help="sw1: ~50-150 candidates/img; dense: head biases raised so ~10^4 rows/img pass conf (BASELINE config 5)")
     args = ap.parse_args()
 
     from yolo_v3_amd import YoloNet, WeightManager, Detector, synth, arch, dist as ydist, _ffi
@@ -99,7 +101,7 @@ def main():
     codes = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3}
 
     # ---- model + data (synthetic SW-1 weights, synthetic scenes; both bit-reproducible)
-    stream = synth.weight_stream()
+    stream = synth.weight_stream() if args.weights == "sw1" else synth.dense_weight_stream()
     net = YoloNet((args.size, args.size)).eval()
     assert WeightManager(net).load_stream(stream) == stream.size
     net = net.to(dev)
@@ -191,8 +193,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "ms_per_img": round(ms_per_step / B, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.dtype], "data": "synthetic",
-            "config": {"workload": "%dx%d bs=%d per GPU, synthetic scenes, SW-1 synthetic weights, conf=%.2f nms=%.2f"
-                                   % (args.size, args.size, B, args.conf, args.nms),
+            "config": {"workload": "%dx%d bs=%d per GPU, synthetic scenes, %s synthetic weights, conf=%.2f nms=%.2f"
+                                   % (args.size, args.size, B, {"sw1": "SW-1", "dense": "SW-dense"}[args.weights], args.conf, args.nms),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "boxes_kept_first_images": kept4},
             "roofline": {"bound": "mfma", "kernel": "%s (74 launches/step)" % KERNEL_NAME[args.dtype],

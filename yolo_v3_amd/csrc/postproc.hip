@@ -74,69 +74,87 @@ __global__ void zero_kernel(int* a, int na, int* b, int nb) {
 template <bool EVAL>
 __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ dets, int N, int C, float thr, bool prob,
                                                      u64* keys, int* segcnt, int max_cand, int* counts) {
+    extern __shared__ int hist[];                 // per-block class histogram: one global atomic per class per block
     const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) hist[c] = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int row0 = wave * 64;
-    if (row0 >= N) return;
     const int attrib = 5 + C;
     const float* img = dets + (size_t)b * N * attrib;
-    const int row = row0 + lane;
-    float conf = 0.f;
-    if (row < N) conf = img[(size_t)row * attrib + 4];
-    // `prob`: the caller guarantees cls in [0,1] (sigmoid outputs) => cls*conf <= conf (rounding is
-    // monotonic), so only rows with conf > thr can pass and the others are never read.
-    u64 todo = __ballot(row < N && (!prob || conf > thr));
     u64* kb = keys + (size_t)b * max_cand;
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int r = row0 + src;
-        const float cf = __shfl(conf, src);
-        const float* p = img + (size_t)r * attrib + 5;
-        if (!EVAL) {
-            float best = -INFINITY; int bidx = 0x7fffffff; bool nan = false;
-            for (int c = lane; c < C; c += 64) {
-                const float s = p[c] * cf;                         // utils.py:233
-                nan |= (s != s);
-                if (s > best) { best = s; bidx = c; }              // first index wins within a lane
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(bidx, off);
-                if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-            }
-            nan = __any(nan);                                       // torch.max propagates NaN -> not > thr
-            if (!nan && best > thr && lane == 0) {                  // utils.py:243
-                const int slot = atomicAdd(&counts[b], 1);
-                if (slot < max_cand) {
-                    kb[slot] = make_key(bidx, best, r);
-                    atomicAdd(&segcnt[b * C + bidx], 1);
+    if (row0 < N) {
+        const int row = row0 + lane;
+        float conf = 0.f;
+        if (row < N) conf = img[(size_t)row * attrib + 4];
+        // `prob`: the caller guarantees cls in [0,1] (sigmoid outputs) => cls*conf <= conf (rounding is
+        // monotonic), so only rows with conf > thr can pass and the others are never read.
+        u64 todo = __ballot(row < N && (!prob || conf > thr));
+        float mybest = -INFINITY; int mycls = 0;      // lane L keeps the result of row row0+L (non-eval mode)
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int r = row0 + src;
+            const float cf = __shfl(conf, src);
+            const float* p = img + (size_t)r * attrib + 5;
+            if (!EVAL) {
+                float best = -INFINITY; int bidx = 0x7fffffff; bool nan = false;
+                for (int c = lane; c < C; c += 64) {
+                    const float s = p[c] * cf;                         // utils.py:233
+                    nan |= (s != s);
+                    if (s > best) { best = s; bidx = c; }              // first index wins within a lane
                 }
-            }
-        } else {
-            for (int c0 = 0; c0 < C; c0 += 64) {
-                const int c = c0 + lane;
-                float s = -1.f;
-                if (c < C) s = p[c] * cf;
-                const bool pass = s > thr;                          // utils.py:238
-                const u64 pm = __ballot(pass);
-                if (pm) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&counts[b], __popcll(pm));
-                    base = __shfl(base, 0);
-                    if (pass) {
-                        const int slot = base + __popcll(pm & ((1ull << lane) - 1));
-                        if (slot < max_cand) {
-                            kb[slot] = make_key(c, s, r);
-                            atomicAdd(&segcnt[b * C + c], 1);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ob = __shfl_xor(best, off);
+                    const int oi = __shfl_xor(bidx, off);
+                    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                }
+                nan = __any(nan);                                       // torch.max propagates NaN -> not > thr
+                if (lane == src && !nan) { mybest = best; mycls = bidx; }
+            } else {
+                for (int c0 = 0; c0 < C; c0 += 64) {
+                    const int c = c0 + lane;
+                    float s = -1.f;
+                    if (c < C) s = p[c] * cf;
+                    const bool pass = c < C && s > thr;                 // utils.py:238
+                    const u64 pm = __ballot(pass);
+                    if (pm) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&counts[b], __popcll(pm));
+                        base = __shfl(base, 0);
+                        if (pass) {
+                            const int slot = base + __popcll(pm & ((1ull << lane) - 1));
+                            if (slot < max_cand) {
+                                kb[slot] = make_key(c, s, r);
+                                atomicAdd(&hist[c], 1);
+                            }
                         }
                     }
                 }
             }
         }
+        if (!EVAL) {
+            const bool pass = mybest > thr;                             // utils.py:243
+            const u64 pm = __ballot(pass);
+            if (pm) {                                                   // ONE counter atomic per wave
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&counts[b], __popcll(pm));
+                base = __shfl(base, 0);
+                if (pass) {
+                    const int slot = base + __popcll(pm & ((1ull << lane) - 1));
+                    if (slot < max_cand) {
+                        kb[slot] = make_key(mycls, mybest, row);
+                        atomicAdd(&hist[mycls], 1);
+                    }
+                }
+            }
+        }
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        if (hist[c]) atomicAdd(&segcnt[b * C + c], hist[c]);
 }
 
 // ------------------------------------------------------------------------------ NMS workspace
@@ -258,40 +276,63 @@ __global__ __launch_bounds__(256) void mask_kernel(const int* __restrict__ count
     }
 }
 
-// Greedy scan of one (image, class) segment by one wave (reference utils.py:180-190).
-__global__ __launch_bounds__(64) void scan_kernel(const int* __restrict__ counts, int max_cand, NmsWs ws, int max_n, int C) {
-    extern __shared__ u64 remv[];          // one bit per sorted position of the image
+// Greedy scan of one (image, class) segment (reference utils.py:180-190), 64 boxes (one mask word) per
+// step.  Wave 0 resolves the in-word chain on scalar registers (one iteration per KEPT box); then all four
+// waves OR the kept rows' mask words into the removed set of the later words: wave v takes rows i = v mod 4,
+// every lane issues its 16 row loads unconditionally (masked afterwards) so they pipeline instead of
+// serialising on memory latency.
+__global__ __launch_bounds__(256) void scan_kernel(const int* __restrict__ counts, int max_cand, NmsWs ws, int max_n, int C) {
+    extern __shared__ u64 remv[];          // [nw] one bit per sorted position of the image, + [nw] = keep word
     const int b = blockIdx.y, c = blockIdx.x;
     const int n = min(min(counts[b], max_cand), max_n);
     int s0 = ws.segoff[b * (C + 1) + c], s1 = ws.segoff[b * (C + 1) + c + 1];
     s0 = min(s0, n); s1 = min(s1, n);
     if (s1 <= s0) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int w_lo = s0 >> 6, w_hi = (s1 - 1) >> 6;
-    for (int w = w_lo + lane; w <= w_hi; w += 64) remv[w] = 0;
+    u64* keepw = remv + ws.nw;
+    for (int w = w_lo + (int)threadIdx.x; w <= w_hi; w += 256) remv[w] = 0;
+    __syncthreads();
     const size_t base = (size_t)b * max_n;
     for (int w = w_lo; w <= w_hi; ++w) {
-        const int p = w * 64 + lane;
-        const bool inseg = p >= s0 && p < s1;
-        u64 diag = 0; bool valid = false;
-        if (inseg) { diag = ws.mask[(base + p) * ws.nw + w]; valid = ws.svalid[base + p] != 0; }
-        u64 dead = remv[w] | ~__ballot(valid);
-        u64 keepm = 0;
-        for (int i = 0; i < 64; ++i) {
-            const u64 di = __shfl(diag, i);
-            if (!((dead >> i) & 1ull)) { keepm |= 1ull << i; dead |= di; }
-        }
-        if (inseg) ws.keep[base + p] = (unsigned char)((keepm >> lane) & 1ull);
-        // propagate the kept rows of this word to the later words of the segment
-        for (int w2 = w + 1 + lane; w2 <= w_hi; w2 += 64) {
-            u64 acc = 0, km = keepm;
-            while (km) {
-                const int i = __ffsll((long long)km) - 1;
-                km &= km - 1;
-                acc |= ws.mask[(base + (size_t)w * 64 + i) * ws.nw + w2];
+        if (wv == 0) {
+            const int p = w * 64 + lane;
+            const bool inseg = p >= s0 && p < s1;
+            u64 diag = 0; bool valid = false;
+            if (inseg) { diag = ws.mask[(base + p) * ws.nw + w]; valid = ws.svalid[base + p] != 0; }
+            // everything below is wave-uniform: keep it in SGPRs (readfirstlane / readlane, no LDS crossbar)
+            const u64 rw = remv[w];
+            u64 dead = (((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(rw >> 32))) << 32 |
+                        (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)rw)) | ~__ballot(valid);
+            u64 keepm = 0;
+            u64 cand = ~dead;
+            const int dlo = (int)diag, dhi = (int)(diag >> 32);
+            while (cand) {                                   // one step per KEPT box, not per box
+                const int i = __ffsll((long long)cand) - 1;
+                keepm |= 1ull << i;
+                const u64 di = ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, i) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, i);
+                dead |= di;
+                cand = ~dead & ~((2ull << i) - 1ull);        // live boxes after i
             }
-            remv[w2] |= acc;
+            if (inseg) ws.keep[base + p] = (unsigned char)((keepm >> lane) & 1ull);
+            if (lane == 0) keepw[0] = keepm;
         }
+        __syncthreads();
+        if (w < w_hi) {
+            const u64 km = keepw[0];
+            for (int w2 = w + 1 + lane; w2 <= w_hi; w2 += 64) {
+                u64 acc = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = 4 * k + wv;
+                    const int r = min(w * 64 + i, n - 1);                    // clamp: rows past the end are masked off
+                    const u64 m = ws.mask[(base + r) * ws.nw + w2];
+                    acc |= ((km >> i) & 1ull) ? m : 0ull;
+                }
+                if (acc) atomicOr(&remv[w2], acc);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -379,8 +420,9 @@ extern "C" int yv3_postproc_filter(const float* dets, int B, int N, int num_clas
     YV3_CHECK_LAUNCH();
     const dim3 grid((unsigned)yv3_ceil_div(N, 256), (unsigned)B);
     const bool prob = (mode & YV3_PP_PROB) != 0 && conf_thr >= 0.f;
-    if (mode & YV3_PP_EVAL) hipLaunchKernelGGL(filter_kernel<true>, grid, dim3(256), 0, s, dets, N, num_class, conf_thr, prob, keys, segcnt, max_cand, cand_counts);
-    else                    hipLaunchKernelGGL(filter_kernel<false>, grid, dim3(256), 0, s, dets, N, num_class, conf_thr, prob, keys, segcnt, max_cand, cand_counts);
+    const size_t hl = (size_t)num_class * sizeof(int);
+    if (mode & YV3_PP_EVAL) hipLaunchKernelGGL(filter_kernel<true>, grid, dim3(256), hl, s, dets, N, num_class, conf_thr, prob, keys, segcnt, max_cand, cand_counts);
+    else                    hipLaunchKernelGGL(filter_kernel<false>, grid, dim3(256), hl, s, dets, N, num_class, conf_thr, prob, keys, segcnt, max_cand, cand_counts);
     YV3_CHECK_LAUNCH();
     return 0;
 }
@@ -410,9 +452,9 @@ extern "C" int yv3_postproc_nms(const float* dets, int B, int N, int num_class, 
         if (mb > 1024) mb = 1024;
         hipLaunchKernelGGL(mask_kernel, dim3((unsigned)mb, B), dim3(256), 0, s, cand_counts, max_cand, ws, max_n, nms_thr);
         YV3_CHECK_LAUNCH();
-        const size_t lds = (size_t)((max_n + 63) / 64) * 8;
+        const size_t lds = (size_t)((max_n + 63) / 64 + 1) * 8;
         if (lds > 64 * 1024) return YV3_ESHAPE;
-        hipLaunchKernelGGL(scan_kernel, dim3(num_class, B), dim3(64), lds, s, cand_counts, max_cand, ws, max_n, num_class);
+        hipLaunchKernelGGL(scan_kernel, dim3(num_class, B), dim3(256), lds, s, cand_counts, max_cand, ws, max_n, num_class);
         YV3_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, s, cand_counts, max_cand, ws, max_n, out_boxes, cap, out_counts);
