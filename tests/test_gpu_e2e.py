@@ -27,10 +27,13 @@ def _input(g, name):
     return torch.from_numpy(synth.images(b, s, int(g[name + "_seed"][0])))
 
 
+@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3])
 @pytest.mark.parametrize("name", ["dog416", "u416", "u608"])
-def test_forward_and_boxes_vs_reference_golden(golden_dir, net, name):
-    """BASELINE configs[0]/[1]-shaped cases.  Tolerance: 1e-4 * max(1,|ref|) on every detection
-    value and every final box column (north-star: "within 1e-4 fp32"); counts and classes exact."""
+def test_forward_and_boxes_vs_reference_golden(golden_dir, net, name, mode):
+    """BASELINE configs[0]/[1]-shaped cases, in both fp32 math modes (exact fp32 MFMA and the bf16x3
+    split).  Tolerance: 1e-4 * max(1,|ref|) on every detection value and every final box column
+    (north-star: "within 1e-4 fp32"); counts and classes exact."""
+    net.math_mode = mode
     g = np.load(os.path.join(golden_dir, "e2e.npz"))
     x = _input(g, name).cuda()
     with torch.no_grad():
@@ -53,7 +56,7 @@ def test_forward_and_boxes_vs_reference_golden(golden_dir, net, name):
     for i, (r, f) in enumerate(zip(res, fused)):
         assert torch.equal(r, f)
         worst = max(worst, match_boxes(r, g["%s_boxes%d" % (name, i)], TOL))
-    print("%s: max detection err %.3g, max box err %.3g" % (name, err, worst))
+    print("%s mode %d: max detection err %.3g, max box err %.3g" % (name, mode, err, worst))
 
 
 def test_eval_mode_vs_reference_golden(golden_dir, net):

@@ -19,7 +19,7 @@ from .utils import PostProcessor
 
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
-                 max_cand=None, cap=None, dtype=_ffi.F32, graph=False):
+                 max_cand=None, cap=None, dtype=None, graph=False):
         self.net = net
         self.shape = (batch, 3, height, width)
         self.conf, self.nms_thr, self.is_eval, self.use_nms = obj_conf_thr, nms_thr, is_eval, use_nms
@@ -90,7 +90,7 @@ def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=F
         from .utils import postprocessing
         with torch.no_grad():
             return postprocessing(net.forward_cat(imgs), net.numClass, obj_conf_thr, nms_thr, True, use_nms)
-    key = (tuple(imgs.shape), imgs.device, float(obj_conf_thr), float(nms_thr), bool(is_eval), bool(use_nms))
+    key = (tuple(imgs.shape), imgs.device, float(obj_conf_thr), float(nms_thr), bool(is_eval), bool(use_nms), net.math_mode)
     cache = net.__dict__.setdefault("_detectors", {})
     det = cache.get(key)
     if det is None:
