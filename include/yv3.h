@@ -181,6 +181,27 @@ int yv3_postproc_nms(const float* dets, int B, int N, int num_class, float nms_t
                      float* out_boxes, int cap, int* out_counts,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Neighbours of the hot path: input preparation and box un-mapping.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces utils.letterbox_image + the /255, HWC->CHW of utils.load_image (utils.py:44-72):
+ * img_hwc uint8 RGB [H,W,3] (device) -> out_chw fp32 [3,out_h,out_w] in [0,1]: bicubic resize (cv2
+ * INTER_CUBIC convention, A=-0.75, no antialias) to box = int(size*min(out_w/W,out_h/H)), centred
+ * (offset out/2 - box/2, utils.py:34-42) on a 128-grey canvas.  Pass out_chw = batch + b*3*out_h*out_w. */
+int yv3_letterbox(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
+                  void* stream);
+
+/* Replaces boundingbox.correct_yolo_boxes (boundingbox.py:139-149) = letterbox_reverse (:95-116) or
+ * rescale_bbox (:119-137) followed by x1y1x2y2 -> xywh.  boxes [B][cap][ld] with x1,y1,x2,y2 in the
+ * first four columns (e.g. the [B,cap,7] output of yv3_postproc_nms, ld = 7); counts [B] valid rows per
+ * image (NULL: all cap rows); org_wh [B][2] int32 original (width,height) per image (device).
+ * out [B][cap][4] in original-image pixels, clipped to the image like the reference: x,y,w,h
+ * (out_xyxy = 0, what correct_yolo_boxes returns) or the intermediate x1,y1,x2,y2 (out_xyxy = 1,
+ * what letterbox_reverse / rescale_bbox return). */
+int yv3_correct_boxes(const float* boxes, int B, int cap, int ld, const int* counts, const int* org_wh,
+                      int img_w, int img_h, int is_letterbox, int out_xyxy, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,6 +277,25 @@ def main():
     print("G5 dog eval boxes", tuple(res[0].shape))
     np.savez_compressed(os.path.join(GOLD, "e2e.npz"), **g5)
 
+    # ---------------------------------------------------------------- G7: neighbours of the path
+    g7 = {}
+    raw = synth.uniform(701, 1, 60 * 4, -40.0, 460.0).reshape(60, 4)
+    boxes = np.stack((np.minimum(raw[:, 0], raw[:, 2]), np.minimum(raw[:, 1], raw[:, 3]),
+                      np.maximum(raw[:, 0], raw[:, 2]), np.maximum(raw[:, 1], raw[:, 3])), 1).astype(np.float32)
+    boxes[7] = 0.0                                    # all-zero row: left untouched by the reference (mask)
+    g7["boxes"] = boxes
+    cases = [(602, 452, 416, 416), (640, 480, 608, 608), (333, 500, 416, 416), (1920, 1080, 416, 416), (416, 416, 416, 416)]
+    g7["cases"] = np.array(cases, dtype=np.int32)
+    for ci, (ow, oh, iw, ih) in enumerate(cases):
+        for lb in (0, 1):
+            out = boundingbox.correct_yolo_boxes(torch.from_numpy(boxes.copy()), ow, oh, iw, ih, bool(lb))
+            g7["out_%d_%d" % (ci, lb)] = out.numpy().astype(np.float32)
+        g7["xyxy_%d" % ci] = boundingbox.letterbox_reverse(torch.from_numpy(boxes.copy()), ow, oh, iw, ih).numpy()
+        g7["rescale_%d" % ci] = boundingbox.rescale_bbox(torch.from_numpy(boxes.copy()), ow, oh, iw, ih).numpy()
+        g7["trans_%d" % ci] = np.array(utils.letterbox_transforms((ow, oh), (iw, ih)), dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "neighbours.npz"), **g7)
+    print("G7 done")
+
     # ---------------------------------------------------------------- G6: per-layer probes (bring-up aid)
     stats = {}
     hooks = []

@@ -286,3 +286,68 @@ def detect(sd, imgs, num_classes=80, obj_conf_thr=0.5, nms_thr=0.4, is_eval=Fals
     with torch.no_grad():
         d1, d2, d3 = yolonet_forward(sd, imgs, anchors, num_classes)
         return postprocess(torch.cat((d1, d2, d3), 1), num_classes, obj_conf_thr, nms_thr, is_eval, use_nms)
+
+
+# --------------------------------------------------------------------------- neighbours of the path
+def letterbox_transforms(inner_dim, outer_dim):
+    """reference utils.py:34-42."""
+    ow, oh = outer_dim
+    iw, ih = inner_dim
+    ratio = min(ow / iw, oh / ih)
+    bw, bh = int(iw * ratio), int(ih * ratio)
+    return bw, bh, (ow // 2) - (bw // 2), (oh // 2) - (bh // 2), ratio
+
+
+def _cubic_weights(t):
+    A = -0.75
+    w0 = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
+    w1 = ((A + 2) * t - (A + 3)) * t * t + 1
+    w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
+    return np.stack((w0, w1, w2, 1 - w0 - w1 - w2), -1)
+
+
+def letterbox_image(img, dim):
+    """reference utils.py:44-72 (letterbox_image + the /255, CHW of load_image) with cv2.resize(INTER_CUBIC)
+    restated in float arithmetic (A=-0.75, half-pixel centres, replicate border, no antialias).  cv2 is not
+    available here, so agreement with cv2's fixed-point uint8 path is UNPINNED (may differ by 1 LSB).
+    img: uint8 [H,W,3]; dim = (w,h).  Returns float32 [3,h,w] in [0,1]."""
+    H, W = img.shape[:2]
+    ow, oh = dim
+    bw, bh, bx, by, _ = letterbox_transforms((W, H), (ow, oh))
+    fx = (np.arange(bw, dtype=np.float32) + np.float32(0.5)) * (np.float32(W) / np.float32(bw)) - np.float32(0.5)
+    fy = (np.arange(bh, dtype=np.float32) + np.float32(0.5)) * (np.float32(H) / np.float32(bh)) - np.float32(0.5)
+    ix, iy = np.floor(fx).astype(np.int64), np.floor(fy).astype(np.int64)
+    wx = _cubic_weights((fx - ix).astype(np.float64))
+    wy = _cubic_weights((fy - iy).astype(np.float64))
+    src = img.astype(np.float64)
+    cols = np.clip(ix[:, None] + np.arange(-1, 3)[None, :], 0, W - 1)          # [bw,4]
+    rows = np.clip(iy[:, None] + np.arange(-1, 3)[None, :], 0, H - 1)          # [bh,4]
+    tmp = (src[:, cols, :] * wx[None, :, :, None]).sum(2)                       # [H,bw,3]
+    box = (tmp[rows, :, :] * wy[:, :, None, None]).sum(1)                       # [bh,bw,3]
+    box = np.clip(np.rint(box), 0, 255)
+    canvas = np.full((oh, ow, 3), 128.0)
+    canvas[by:by + bh, bx:bx + bw] = box
+    return torch.from_numpy((canvas.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())
+
+
+def correct_yolo_boxes(bboxes, org_w, org_h, img_w, img_h, is_letterbox=False):
+    """reference boundingbox.py:95-149: un-letterbox (or un-resize) x1y1x2y2 boxes, clip, convert to xywh."""
+    if len(bboxes) == 0:
+        return bboxes
+    b = bboxes.clone().float()
+    mask = b.sum(-1) != 0
+    if is_letterbox:
+        ratio = min(img_w / org_w, img_h / org_h)
+        rw, rh = int(org_w * ratio), int(org_h * ratio)
+        xp, yp = (img_w - rw) // 2, (img_h - rh) // 2
+        b[mask, 0] = torch.clamp((b[mask, 0] - xp) / ratio, 0, org_w)
+        b[mask, 2] = torch.clamp((b[mask, 2] - xp) / ratio, 0, org_w)
+        b[mask, 1] = torch.clamp((b[mask, 1] - yp) / ratio, 0, org_h)
+        b[mask, 3] = torch.clamp((b[mask, 3] - yp) / ratio, 0, org_h)
+    else:
+        rx, ry = img_w / org_w, img_h / org_h
+        b[mask, 0] = torch.clamp(b[mask, 0] / rx, 0, org_w)
+        b[mask, 2] = torch.clamp(b[mask, 2] / rx, 0, org_w)
+        b[mask, 1] = torch.clamp(b[mask, 1] / ry, 0, org_h)
+        b[mask, 3] = torch.clamp(b[mask, 3] / ry, 0, org_h)
+    return torch.stack((b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]), -1)

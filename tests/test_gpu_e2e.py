@@ -195,3 +195,23 @@ def test_weights_change_is_picked_up(net, sw1_stream):
     assert not torch.equal(a[:, :507], b[:, :507]) and torch.equal(a[:, 507:], b[:, 507:])
     net.load_state_dict(sd)
     assert torch.equal(net.forward_cat(x), a)
+
+
+def test_predict_idiom_matches_oracle_composition(net):
+    """reference test.py:28-46 end to end for images of different sizes: letterbox -> net -> NMS -> boxes in
+    the ORIGINAL image.  Checked against the oracle composition on the SAME letterboxed input: classes/counts
+    exact, xywh within 1e-4 * image size."""
+    from yolo_v3_amd import predict, letterbox_batch
+    net.math_mode = _ffi.F32X3
+    base = (synth.images(2, 416, 123) * 255).astype(np.uint8)
+    imgs = [np.ascontiguousarray(base[0].transpose(1, 2, 0)[:300, :]), np.ascontiguousarray(base[1].transpose(1, 2, 0)[:, :250])]
+    preds = predict(net, imgs, (416, 416), obj_conf_thr=0.1)
+    batch, _ = letterbox_batch(imgs, (416, 416))
+    sd_boxes = detect(net, batch, obj_conf_thr=0.1)
+    assert len(preds) == 2 and len(sd_boxes) == 2 and min(len(b) for b in sd_boxes) > 0
+    for i, im in enumerate(imgs):
+        ref = oc.correct_yolo_boxes(sd_boxes[i][:, :4], im.shape[1], im.shape[0], 416, 416, True)
+        assert preds[i].shape == (len(sd_boxes[i]), 5)
+        assert torch.equal(preds[i][:, 0], sd_boxes[i][:, 6])
+        assert torch.equal(preds[i][:, 1:], ref)                    # same fp32 ops on the same boxes -> bitwise
+        assert float(preds[i][:, 1].min()) >= 0 and float((preds[i][:, 1] + preds[i][:, 3]).max()) <= im.shape[1] + 1e-3

@@ -304,3 +304,43 @@ def test_head_conv_255_and_asymmetric_layout():
     out = grp.cuda()(x.cuda()).cpu()
     assert out.shape == (2, 255, 5, 7)
     assert torch.equal(out.double(), ref)            # small integers: exact in fp32
+
+
+# ----------------------------------------------------------------------------- neighbours of the path
+def test_correct_yolo_boxes_bit_exact_vs_reference(golden_dir):
+    """boundingbox.py:95-149 on the GPU: un-letterbox / un-resize + clip + xywh, bitwise equal to the reference."""
+    from yolo_v3_amd import correct_yolo_boxes, letterbox_reverse, rescale_bbox
+    g = np.load(os.path.join(golden_dir, "neighbours.npz"))
+    boxes = torch.from_numpy(g["boxes"])
+    for ci, (ow, oh, iw, ih) in enumerate(g["cases"].tolist()):
+        for lb in (0, 1):
+            out = correct_yolo_boxes(boxes.cuda(), ow, oh, iw, ih, bool(lb))
+            assert out.is_cuda and np.array_equal(out.cpu().numpy(), g["out_%d_%d" % (ci, lb)]), (ci, lb)
+        assert np.array_equal(letterbox_reverse(boxes, ow, oh, iw, ih).numpy(), g["xyxy_%d" % ci])       # CPU in -> CPU out
+        assert np.array_equal(rescale_bbox(boxes.cuda(), ow, oh, iw, ih).cpu().numpy(), g["rescale_%d" % ci])
+    assert len(correct_yolo_boxes(torch.zeros(0, 4), 10, 10, 416, 416, True)) == 0
+
+
+def test_letterbox_vs_oracle(golden_dir):
+    """utils.py:34-72 on the GPU.  cv2 is absent, so the check is against the oracle's float restatement of
+    cv2.INTER_CUBIC (parity with cv2's fixed-point path: unpinned).  fp32 vs fp64 weights may round a .5 case
+    differently: allow <= 1 LSB on at most 0.5 % of the pixels; geometry (box position, grey padding) exact."""
+    from yolo_v3_amd import letterbox_batch, letterbox_transforms
+    imgs = [(synth.uniform01(31 + i, 9, h * w * 3).reshape(h, w, 3) * 255).astype(np.uint8) for i, (h, w) in
+            enumerate([(452, 602), (300, 200), (100, 640), (416, 416), (37, 53)])]
+    # smooth structure so that bicubic overshoot / clipping paths are exercised too
+    imgs[0][100:200, 150:400] = 255; imgs[0][250:300, :] = 0
+    batch, trans = letterbox_batch(imgs, (416, 416))
+    assert batch.shape == (5, 3, 416, 416) and batch.is_cuda
+    for i, im in enumerate(imgs):
+        ref = oc.letterbox_image(im, (416, 416))
+        got = batch[i].cpu()
+        d = ((got - ref).abs() * 255.0).round()
+        assert float(d.max()) <= 1.0, float(d.max())
+        assert float((d > 0).float().mean()) <= 5e-3, float((d > 0).float().mean())
+        bw, bh, bx, by, ratio = letterbox_transforms((im.shape[1], im.shape[0]), (416, 416))
+        assert trans[i].tolist()[:4] == [bw, bh, bx, by]
+        pad = torch.ones(416, 416, dtype=torch.bool); pad[by:by + bh, bx:bx + bw] = False
+        assert torch.equal(got[:, pad], torch.full_like(got[:, pad], 128.0 / 255.0))
+    # 602x452 -> 416x312 at y offset 52 (SURVEY config 1)
+    assert trans[0].tolist()[:4] == [416, 312, 0, 52]

@@ -76,8 +76,26 @@ def test_pytorch_format_roundtrip(tmp_path, sw1_stream):
     net2.loadWeight(p, "pytorch")
     for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
         assert torch.equal(a, b), k
-    with pytest.raises(NotImplementedError):
-        net.saveWeight(p, "darknet")                                  # as the reference (darknet.py:237-238)
+
+
+def test_darknet_save_is_byte_identical(tmp_path, sw1_stream):
+    """saveWeight(format='darknet') (the reference raises NotImplementedError, darknet.py:237-238):
+    the file must equal the one synth.write_darknet_weights produces -- which the REFERENCE loader reads back
+    correctly (golden G1) -- and round-trip through our own loader."""
+    net = load_sw1_net(sw1_stream)
+    a, b = str(tmp_path / "a.weights"), str(tmp_path / "b.weights")
+    wm = WeightManager(net)
+    wm.saveWeight(a, seen=32013312)
+    synth.write_darknet_weights(b, sw1_stream, seen=32013312)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    net2 = YoloNet((416, 416))
+    wm2 = WeightManager(net2)
+    assert wm2.loadWeight(a) == sw1_stream.size and int(wm2.seen) == 32013312
+    net2.saveWeight(b, "darknet")                                    # keeps the `seen` counter it loaded... via a new manager: 0
+    assert np.array_equal(np.fromfile(b, dtype=np.float32)[5:], sw1_stream)
+    # backbone-only save (darknet53.conv.74-style file)
+    WeightManager(net.feature).saveWeight(b)
+    assert os.path.getsize(b) == 20 + 4 * 40620640
 
 
 def test_cfg_index_map():

@@ -95,3 +95,14 @@ def test_end_to_end_vs_reference(golden_dir, sw1_stream, name):
         ev = oc.postprocess(dets, 80, float(ct), float(nt), True, True)
         assert tuple(ev[0].shape) == tuple(g["dog416_eval_boxes0"].shape)
         np.testing.assert_allclose(ev[0].numpy(), g["dog416_eval_boxes0"], rtol=2e-6, atol=2e-6)
+
+
+def test_neighbour_rows_bitwise_vs_reference(golden_dir):
+    """correct_yolo_boxes (both modes) and letterbox_transforms against the reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "neighbours.npz"))
+    boxes = torch.from_numpy(g["boxes"])
+    for ci, (ow, oh, iw, ih) in enumerate(g["cases"].tolist()):
+        for lb in (0, 1):
+            out = oc.correct_yolo_boxes(boxes, ow, oh, iw, ih, bool(lb))
+            assert np.array_equal(out.numpy(), g["out_%d_%d" % (ci, lb)]), (ci, lb)
+        assert np.array_equal(np.array(oc.letterbox_transforms((ow, oh), (iw, ih)), dtype=np.float64), g["trans_%d" % ci])

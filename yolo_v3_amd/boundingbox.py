@@ -20,3 +20,49 @@ def bbox_cxcywh_to_x1y1x2y2(box):
     if src.data_ptr() != box.data_ptr():
         box.copy_(src)
     return box
+
+
+def _unmap(labels, org_w, org_h, new_w, new_h, is_letterbox, xyxy):
+    """Shared GPU path of letterbox_reverse / rescale_bbox / correct_yolo_boxes for a [n, >=4] tensor (CPU or
+    GPU; the result follows the input device): un-mapped + clipped x1y1x2y2 (xyxy=True) or xywh."""
+    if not isinstance(labels, torch.Tensor):
+        raise TypeError("Labels must be a pytorch tensor")
+    was_cpu = not labels.is_cuda
+    if was_cpu and not torch.cuda.is_available():
+        raise _ffi.Yv3Error("no GPU available: this package has no CPU path")
+    src = labels.detach().float().cuda().contiguous() if was_cpu else labels.detach().float().contiguous()
+    n = src.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=src.device)
+    if n:
+        with torch.cuda.device(src.device):
+            org = torch.tensor([[int(org_w), int(org_h)]], dtype=torch.int32, device=src.device)
+            _ffi.check(_ffi.lib().yv3_correct_boxes(src.data_ptr(), 1, n, src.shape[1], None, org.data_ptr(), int(new_w), int(new_h),
+                                                    int(bool(is_letterbox)), int(bool(xyxy)), out.data_ptr(), _ffi.stream_ptr()),
+                       "yv3_correct_boxes")
+    return out.cpu() if was_cpu else out
+
+
+def correct_yolo_boxes(bboxes, org_w, org_h, img_w, img_h, is_letterbox=False):
+    """x1y1x2y2 boxes in network-input pixels -> xywh in the original image, clipped (reference
+    boundingbox.py:139-149).  Returns a new [n,4] tensor; an empty input is returned unchanged."""
+    if len(bboxes) == 0:
+        return bboxes
+    return _unmap(bboxes[..., :4], org_w, org_h, img_w, img_h, is_letterbox, False)
+
+
+def letterbox_reverse(labels, org_w, org_h, new_w, new_h):
+    """reference boundingbox.py:95-116: undo the letterbox mapping on columns 0..3 (x1,y1,x2,y2), clip to the image."""
+    if len(labels) == 0:
+        return labels
+    out = labels.clone()
+    out[..., :4] = _unmap(labels[..., :4], org_w, org_h, new_w, new_h, True, True)
+    return out
+
+
+def rescale_bbox(labels, org_w, org_h, new_w, new_h):
+    """reference boundingbox.py:119-137: undo a plain resize on columns 0..3 (x1,y1,x2,y2), clip to the image."""
+    if len(labels) == 0:
+        return labels
+    out = labels.clone()
+    out[..., :4] = _unmap(labels[..., :4], org_w, org_h, new_w, new_h, False, True)
+    return out

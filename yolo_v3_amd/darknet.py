@@ -287,7 +287,9 @@ class YoloNet(nn.Module):
         if format == 'pytorch':
             torch.save(self.state_dict(), weights_path)
         elif format == 'darknet':
-            raise NotImplementedError
+            # the reference raises NotImplementedError here (darknet.py:237-238); writing the file completes
+            # the wire format both ways
+            WeightManager(self).saveWeight(weights_path)
 
     def loadWeight(self, weights_path, format='pytorch'):
         if format == 'pytorch':
@@ -330,6 +332,25 @@ class WeightManager:
     def loadWeight(self, weight_path):
         stream = self.read_file(weight_path)
         return self.load_stream(stream)
+
+    def to_stream(self):
+        """The parameters as one float32 numpy stream in darknet file order (inverse of load_stream)."""
+        parts = []
+        for m in self.conv_list:
+            ts = (m.bn.bias, m.bn.weight, m.bn.running_mean, m.bn.running_var, m.conv.weight) if isinstance(m, conv_bn_relu) \
+                else (m.bias, m.weight)
+            parts += [t.detach().float().cpu().contiguous().numpy().ravel() for t in ts]
+        return np.concatenate(parts).astype(np.float32)
+
+    def saveWeight(self, weight_path, seen=None):
+        """Write a darknet ``.weights`` file: int32 (major=0, minor=2, revision=0), int64 ``seen``, float32 stream.
+        ``seen`` defaults to the value read by the last loadWeight (0 if none)."""
+        if seen is None:
+            seen = int(self.seen) if self.seen is not None else 0
+        with open(weight_path, "wb") as fp:
+            np.array([0, 2, 0], dtype=np.int32).tofile(fp)
+            np.array([seen], dtype=np.int64).tofile(fp)
+            self.to_stream().tofile(fp)
 
     def load_stream(self, stream):
         """Consume a float32 stream (numpy) already in memory; returns the number of floats used."""

@@ -133,3 +133,66 @@ def _iou(b1, b2, mode):
             _ffi.check(_ffi.lib().yv3_iou_matrix(g1.data_ptr(), n1, g1.shape[1], g2.data_ptr(), n2, g2.shape[1], mode,
                                                  out.data_ptr(), _ffi.stream_ptr()), "yv3_iou_matrix")
     return out.cpu() if was_cpu else out
+
+
+# ----------------------------------------------------------------------------- input preparation
+def letterbox_transforms(inner_dim, outer_dim):
+    """reference utils.py:34-42: (box_w, box_h, box_x_offset, box_y_offset, ratio) of an aspect-preserving fit of
+    inner_dim = (w,h) into outer_dim = (w,h)."""
+    outer_w, outer_h = outer_dim
+    inner_w, inner_h = inner_dim
+    ratio = min(outer_w / inner_w, outer_h / inner_h)
+    box_w, box_h = int(inner_w * ratio), int(inner_h * ratio)
+    return box_w, box_h, (outer_w // 2) - (box_w // 2), (outer_h // 2) - (box_h // 2), ratio
+
+
+def letterbox_batch(images, dim, device=None):
+    """List of uint8 RGB images ([H,W,3] numpy arrays or tensors, any sizes) -> network input batch
+    ``[B,3,dim_h,dim_w]`` fp32 in [0,1] on the GPU + per-image transforms ``[B,5]`` (box_w, box_h, x, y, ratio).
+
+    One HIP kernel per image does what reference utils.load_image(mode='letterbox') does on the host with cv2
+    (utils.py:44-72): bicubic resize, paste on a 128-grey canvas, /255, HWC -> CHW.  ``dim`` = (w, h)."""
+    if not torch.cuda.is_available():
+        raise _ffi.Yv3Error("no GPU available: this package has no CPU path")
+    dev = torch.device(device if device is not None else "cuda")
+    out_w, out_h = int(dim[0]), int(dim[1])
+    lib = _ffi.lib()
+    batch = torch.empty((len(images), 3, out_h, out_w), dtype=torch.float32, device=dev)
+    trans = []
+    with torch.cuda.device(dev):
+        keep = []
+        for b, img in enumerate(images):
+            t = img if isinstance(img, torch.Tensor) else torch.from_numpy(img)
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise _ffi.Yv3Error("images must be uint8 [H,W,3] RGB")
+            t = t.to(dev).contiguous()
+            keep.append(t)
+            H, W = t.shape[0], t.shape[1]
+            _ffi.check(lib.yv3_letterbox(t.data_ptr(), H, W, batch.data_ptr() + b * 3 * out_h * out_w * 4, out_h, out_w,
+                                         _ffi.stream_ptr()), "yv3_letterbox")
+            trans.append(list(letterbox_transforms((W, H), (out_w, out_h))))
+        torch.cuda.current_stream().synchronize()      # `keep` (device copies of the inputs) may now be released
+    return batch, torch.tensor(trans, dtype=torch.float32)
+
+
+def letterbox_image(img, dim):
+    """reference utils.py:44-56 signature: HWC uint8 RGB ``img`` -> (HWC image with values 0..255, transform tensor)."""
+    batch, trans = letterbox_batch([img], dim)
+    hwc = (batch[0] * 255.0).round().permute(1, 2, 0).to(torch.int64).cpu().numpy()
+    return hwc, trans[0]
+
+
+def load_image(img, mode=None, dim=None):
+    """reference utils.py:59-72 with the decode step left to the caller: ``img`` is a path (decoded with PIL) or
+    an HWC uint8 RGB array.  Returns (CHW fp32 tensor in [0,1] on the GPU, transform or None)."""
+    if isinstance(img, str):
+        from PIL import Image
+        import numpy as np
+        img = np.asarray(Image.open(img).convert("RGB"))
+    if mode == 'letterbox' and dim is not None:
+        batch, trans = letterbox_batch([img], dim)
+        return batch[0], trans[0]
+    if mode is not None:
+        raise NotImplementedError("only mode='letterbox' (or None) is provided")
+    t = img if isinstance(img, torch.Tensor) else torch.from_numpy(img)
+    return t.cuda().float().permute(2, 0, 1) / 255, None
