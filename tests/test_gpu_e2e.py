@@ -215,3 +215,28 @@ def test_predict_idiom_matches_oracle_composition(net):
         assert torch.equal(preds[i][:, 0], sd_boxes[i][:, 6])
         assert torch.equal(preds[i][:, 1:], ref)                    # same fp32 ops on the same boxes -> bitwise
         assert float(preds[i][:, 1].min()) >= 0 and float((preds[i][:, 1] + preds[i][:, 3]).max()) <= im.shape[1] + 1e-3
+
+
+@pytest.mark.parametrize("nc,size,mode", [(20, 320, _ffi.F32X3), (1, 352, _ffi.F32), (20, 320, _ffi.F32)])
+def test_other_class_counts_and_sizes(nc, size, mode):
+    """Custom-data shapes (reference README: VOC 20 classes, x-wing 1 class): head width 3*(5+nc) is no longer
+    255, input size is not 416/608.  Whole net vs the oracle at 1e-4, decisions exact on identical detections."""
+    from yolo_v3_amd import YoloNet, WeightManager
+    stream = synth.weight_stream(num_class=nc, seed=77)
+    net = YoloNet((size, size), numClass=nc).eval()
+    assert WeightManager(net).load_stream(stream) == stream.size
+    net = net.cuda()
+    net.math_mode = mode
+    x = torch.from_numpy(synth.images(2, size, 9))
+    sd, _ = oc.state_dict_from_stream(stream, nc)
+    with torch.no_grad():
+        ref = torch.cat(oc.yolonet_forward(sd, x, num_class=nc), 1)
+        dets = net.forward_cat(x.cuda())
+    assert dets.shape == ref.shape == (2, 3 * 21 * (size // 32) ** 2, 5 + nc)
+    assert_close_rel(dets.cpu(), ref, TOL, "nc=%d size=%d" % (nc, size))
+    thr = 0.3
+    exp = oc.postprocess(dets.cpu(), nc, thr, 0.4)
+    got = detect(net, x.cuda(), nc, thr, 0.4)
+    check_result_convention(got, exp)
+    for a, b in zip(got, exp):
+        assert torch.equal(a, b)
