@@ -253,6 +253,23 @@ def test_conv_bf16_mode_vs_fp64(cin, cout, k, s, B, H, W):
     assert_close_rel(out, ref, 2e-2, "bf16 conv %s" % ((cin, cout, k, s),))
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(128, 256, 5, 13, 13), (64, 128, 70, 26, 26), (32, 64, 2, 19, 21), (512, 1024, 24, 13, 13), (256, 512, 33, 26, 26)])
+def test_conv_k3s1_tap_reuse_kernel(cin, cout, B, H, W, monkeypatch):
+    """Opt-in 3x3/stride-1 kernel that stages ONE activation tile per (kh, channel chunk) and reuses it for
+    the three kw taps (csrc/conv_planes_k3s1.hip): must equal the generic plane kernel to fp32 round-off
+    (same products, different accumulation order) and the fp64 reference at 2e-5."""
+    m = _rand_cbr(cin, cout, 3, 1, seed=cin + cout)
+    x = torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(1)) * 2 - 0.5
+    res = torch.rand(B, cout, H, W, generator=torch.Generator().manual_seed(2)) - 0.5
+    ref = _ref_cbr(m, x) + res.double()
+    m = m.cuda()
+    generic = _run_mode(m, x, _ffi.F32X3, res)
+    monkeypatch.setenv("YV3_K3S1", "1")
+    reuse = _run_mode(m, x, _ffi.F32X3, res)
+    assert_close_rel(reuse, ref, 2e-5, "k3s1 conv")
+    assert_close_rel(reuse, generic, 4e-6, "k3s1 vs generic")
+
+
 def test_plane_split_is_exact():
     """fp32 -> 3 bf16 planes -> fp32 is the identity (8+8+8 mantissa bits), including tiny/huge values."""
     g = torch.Generator().manual_seed(5)

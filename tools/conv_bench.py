@@ -25,6 +25,10 @@ for name in names:
     sp = m._spec()
     pc = engine.pack_conv(m, sp, dt)
     xf = torch.rand(B, H, H, cin, device="cuda") - 0.5
+    if os.environ.get("ZERO") == "1":
+        xf.zero_()
+        with torch.no_grad():
+            m.conv.weight.zero_()
     ho, wo = engine.out_hw(H, H, k, s)
     rf = (torch.rand(B, ho, wo, cout, device="cuda") - 0.5) if res else None
     x = engine.to_planes(xf, dt)

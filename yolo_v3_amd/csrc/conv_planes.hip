@@ -20,53 +20,10 @@
 //
 // Replaces the same reference call sites as conv_igemm_f32.hip (darknet.py:43-44, :52-53, :118,
 // :161-162).
-#include "yv3_common.h"
+#include <stdlib.h>
+#include "conv_planes_common.h"
 
 namespace {
-
-__device__ __attribute__((aligned(64))) u16 g_zero_page[64];     // zero-initialised: source of halo rows
-
-struct ConvParamsP {
-    const u16* x;
-    const u16* x2;
-    const u16* w;
-    const float* alpha;
-    const float* beta;
-    const u16* res;
-    void* y;
-    long long xs, x2s, ys;      // plane strides (elements) of x, x2, y/res
-    int H, W, Cin, Cup, Cout;
-    int stride, act;
-    int Ho, Wo, M, K;
-    int nk;                     // K / PBK
-    int ntiles;
-    int tb;                     // rows per packed weight tile
-};
-
-constexpr int PBK = 32;           // K elements per chunk
-constexpr int ROWB = PBK * 2;     // bytes per tile row per plane (64: half a cache line)
-constexpr int SLOTS = PBK / 8;    // 16-byte slots per row
-constexpr int RPG = 64 / SLOTS;   // rows moved by one global_load_lds wave instruction (16)
-
-typedef short bf16x8v __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-__device__ inline unsigned pack2_bf16_rn(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ inline float bf_lo(unsigned q) { return __uint_as_float(q << 16); }
-__device__ inline float bf_hi(unsigned q) { return __uint_as_float(q & 0xffff0000u); }
-
-// bank-conflict swizzle for 64-byte rows read with ds_read_b128: four rows share a 256-byte bank row
-__device__ __host__ inline int swz(int row) { return (row >> 2) & (SLOTS - 1); }
-
-template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32>
 __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvParamsP p) {
@@ -203,11 +160,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                frag[ks][f] = *reinterpret_cast<const bf16x8v*>(st + x_row + fslot + (g / NP) * 32 * ROWB + (g % NP) * A_PLANE); }
     };
 
+#ifdef YV3_TIMELINE
+    unsigned long long tl_wait = 0, tl_bar = 0, tl_body = 0, tl_prev = 0, tl_dma = 0;
+#endif
+#if defined(YV3_PRIO) && YV3_PRIO == 1
+    // the second-dispatched half of an 8-wave workgroup loses issue arbitration (age) to the first half on
+    // every segment and the first half then idles at the barrier; static priority for the younger half
+    if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(YV3_PRIO) && YV3_PRIO == 2
+    if (NW == 8 && wid < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int cur = 0, nxt = D % NSTAGE;
     for (int kc = 0; kc < p.nk; ++kc) {
         // chunk kc must have landed; up to D-1 younger chunks may stay in flight (never a full drain mid-loop)
+#ifdef YV3_TIMELINE
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
         if (kc + D - 1 < p.nk) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();
+#ifdef YV3_TIMELINE
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef YV3_TIMELINE
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        tl_wait += t1 - t0; tl_bar += t2 - t1;
+        if (kc > 0) tl_body += t0 - tl_prev;
+        tl_prev = t2;
+#endif
         st = lds + cur * STAGE;
 #if !defined(YV3_ABLATE) || (YV3_ABLATE != 1)
         const bool more = kc + D < p.nk;
@@ -234,10 +213,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                 }
 #endif
                 if (more) {
+                    // all pieces go out during the FIRST k-step's units: the DMA then has the rest of this chunk's
+                    // MFMAs to land before the wait at the top of the next iteration
+                    constexpr int DU = YV3_DMA_UNITS < KS * NU ? YV3_DMA_UNITS : KS * NU;
 #pragma unroll
-                    for (int g = gu * G / (KS * NU); g < (gu + 1) * G / (KS * NU); ++g) dma_piece(g);
+                    for (int g = (gu < DU ? gu * G / DU : G); g < (gu < DU ? (gu + 1) * G / DU : G); ++g) {
+#ifdef YV3_TIMELINE
+                        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+                        dma_piece(g);
+                        tl_dma += __builtin_amdgcn_s_memtime() - ta;
+#else
+                        dma_piece(g);
+#endif
+                    }
                 }
-#if !defined(YV3_ABLATE) || (YV3_ABLATE != 2)
+#if defined(YV3_ABLATE) && (YV3_ABLATE == 3)
+                {   // keep the fragment reads alive, skip the MFMAs: DMA + LDS-read path only
+                    const int i = u / MT, j = u % MT;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        asm volatile("" :: "v"(frag[ks][i * NP + pl]));
+                        asm volatile("" :: "v"(frag[ks][NT * NP + j * NP + pl]));
+                    }
+                }
+#elif !defined(YV3_ABLATE) || (YV3_ABLATE != 2)
                 const int i = u / MT, j = u % MT;
                 f32x16 c = acc[i][j];
                 const bf16x8v* wf = &frag[ks][i * NP];
@@ -260,84 +259,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
 
-    // ---- epilogue.  D tile of an MFMA: col = lane&31 -> pixel, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> channel.
-    // A lane therefore holds 4 consecutive channels of ONE pixel; storing that directly scatters 8-byte
-    // pieces over 32 rows per instruction.  Instead each wave transposes its WTM x WTN tile through LDS
-    // (the pipeline stages are free now) so that 8 (or 4) neighbouring lanes cover the contiguous channels
-    // of one pixel: residual planes are read and output planes written as full 16-byte-per-lane rows.
-    constexpr int EP = WTN + 4;                       // floats per tile row (+4: conflict-free ds_write_b128)
-    // (launch_cfg sizes the dynamic LDS as max(pipeline, NW * WTM * EP * 4))
-    __syncthreads();                                  // every wave is done with the last stage
-    float* tile = reinterpret_cast<float*>(lds) + wid * (WTM * EP);
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = i * 32 + 8 * g + 4 * lhi;                 // channel inside the wave tile
-                const int n = n0 + wn * WTN + nl;
-                f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-                if (OUT_F32) {          // head conv: cout (255) is not a multiple of 4 -> element-wise
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < p.Cout) { be[q] = p.beta[n + q]; if (p.alpha) al[q] = p.alpha[n + q]; }
-                } else if (n < p.Cout) {
-                    be = *reinterpret_cast<const f32x4*>(p.beta + n);
-                    if (p.alpha) al = *reinterpret_cast<const f32x4*>(p.alpha + n);
-                }
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t = fmaf(acc[i][j][4 * g + q], al[q], be[q]);
-                    if (p.act == YV3_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
-                    v[q] = t;
-                }
-                *reinterpret_cast<f32x4*>(tile + (j * 32 + l31) * EP + nl) = v;
-            }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    constexpr int LPR = WTN / 8;                      // lanes per pixel row (8 channels each)
-    constexpr int RPP = 64 / LPR;                     // pixel rows per pass
-#pragma unroll
-    for (int ps = 0; ps < WTM / RPP; ++ps) {
-        const int r = ps * RPP + lane / LPR;
-        const int cg = (lane % LPR) * 8;
-        const int m = m0 + wm * WTM + r;
-        const int n = n0 + wn * WTN + cg;
-        if (m >= p.M || n >= p.Cout) continue;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const long long o = (long long)m * p.Cout + n;
-        if (OUT_F32) {
-            float* yo = (float*)p.y + o;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (n + q < p.Cout) yo[q] = v[q];
-        } else {
-            if (p.res) {
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {       // planes sum back to the exact fp32 value
-                    const u32x4 q4 = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) { v[2 * h] += bf_lo(q4[h]); v[2 * h + 1] += bf_hi(q4[h]); }
-                }
-            }
-            u16* yo = (u16*)p.y + o;
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                u32x4 q4;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    q4[h] = pack2_bf16_rn(v[2 * h], v[2 * h + 1]);
-                    v[2 * h] -= bf_lo(q4[h]); v[2 * h + 1] -= bf_hi(q4[h]);
-                }
-                *reinterpret_cast<u32x4*>(yo + pl * p.ys) = q4;
-            }
-        }
+#ifdef YV3_TIMELINE
+    if (blockIdx.x == 17 && lane == 0 && p.alpha) {      // debug build only: dump cycle split of one block into alpha[0..]
+        float* dbg = const_cast<float*>(p.alpha);
+        dbg[wid * 4 + 0] = (float)tl_wait; dbg[wid * 4 + 1] = (float)tl_bar; dbg[wid * 4 + 2] = (float)tl_body; dbg[wid * 4 + 3] = (float)tl_dma;
     }
+#endif
+    epilogue_store<NP, BM, BN, WM, WN, OUT_F32>(acc, p, lds, m0, n0, wid, lane);
 }
 
 template <int NP, int BM, int BN, int WM, int WN, int NSTAGE>
@@ -445,6 +373,8 @@ extern "C" int yv3_merge_planes(const void* in, float* out, long long n, int np,
     return 0;
 }
 
+int yv3_conv2d_planes_k3s1(const ConvParamsP* pp, int np, int npad, long long M, hipStream_t s);
+
 int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     ConvParamsP p;
     p.x = (const u16*)d->x; p.x2 = (const u16*)d->x2; p.w = (const u16*)d->w;
@@ -473,6 +403,12 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     p.tb = npad < 128 ? npad : 128;
     if (npad % p.tb) return YV3_ESHAPE;
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
+    // kw-tap reuse kernel (conv_planes_k3s1.hip): 44 % less L2->LDS traffic, same results, but no faster on
+    // MI355X because this MFMA stream is power-limited -- opt-in until that changes.
+    if (k3 && d->stride == 1 && !out_f32 && getenv("YV3_K3S1")) {
+        const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
+        if (rc != -100) return rc;
+    }
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s) \
                                                    : launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s))
     if (npad % 128 == 0) {

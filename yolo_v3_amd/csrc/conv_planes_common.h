@@ -1,0 +1,147 @@
+// Shared pieces of the bf16-plane convolution kernels (conv_planes.hip, conv_planes_k3s1.hip).
+#pragma once
+#include "yv3_common.h"
+
+struct ConvParamsP {
+    const u16* x;
+    const u16* x2;
+    const u16* w;
+    const float* alpha;
+    const float* beta;
+    const u16* res;
+    void* y;
+    long long xs, x2s, ys;      // plane strides (elements) of x, x2, y/res
+    int H, W, Cin, Cup, Cout;
+    int stride, act;
+    int Ho, Wo, M, K;
+    int nk;                     // K / PBK
+    int ntiles;
+    int tb;                     // rows per packed weight tile
+};
+
+namespace {
+
+__device__ __attribute__((aligned(64))) u16 g_zero_page[64];     // zero-initialised: source of halo rows
+
+
+#ifndef YV3_DMA_UNITS
+#define YV3_DMA_UNITS 8
+#endif
+constexpr int PBK = 32;           // K elements per chunk
+constexpr int ROWB = PBK * 2;     // bytes per tile row per plane (64: half a cache line)
+constexpr int SLOTS = PBK / 8;    // 16-byte slots per row
+constexpr int RPG = 64 / SLOTS;   // rows moved by one global_load_lds wave instruction (16)
+
+typedef short bf16x8v __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ inline unsigned pack2_bf16_rn(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ inline float bf_lo(unsigned q) { return __uint_as_float(q << 16); }
+__device__ inline float bf_hi(unsigned q) { return __uint_as_float(q & 0xffff0000u); }
+
+// bank-conflict swizzle for 64-byte rows read with ds_read_b128: four rows share a 256-byte bank row
+__device__ __host__ inline int swz(int row) { return (row >> 2) & (SLOTS - 1); }
+
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+
+// ---- epilogue shared by both kernels: acc[NT][MT] of the wave tile -> BN/activation -> LDS transpose ->
+// residual add -> output planes (or fp32).  `lds` must have NW * WTM * (WTN+4) * 4 bytes available.
+template <int NP, int BM, int BN, int WM, int WN, bool OUT_F32>
+__device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], const ConvParamsP& p,
+                                               unsigned char* lds, int m0, int n0, int wid, int lane) {
+    constexpr int NW = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    (void)NW;
+    // ---- epilogue.  D tile of an MFMA: col = lane&31 -> pixel, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> channel.
+    // A lane therefore holds 4 consecutive channels of ONE pixel; storing that directly scatters 8-byte
+    // pieces over 32 rows per instruction.  Instead each wave transposes its WTM x WTN tile through LDS
+    // (the pipeline stages are free now) so that 8 (or 4) neighbouring lanes cover the contiguous channels
+    // of one pixel: residual planes are read and output planes written as full 16-byte-per-lane rows.
+    constexpr int EP = WTN + 4;                       // floats per tile row (+4: conflict-free ds_write_b128)
+    // (launch_cfg sizes the dynamic LDS as max(pipeline, NW * WTM * EP * 4))
+    __syncthreads();                                  // every wave is done with the last stage
+    float* tile = reinterpret_cast<float*>(lds) + wid * (WTM * EP);
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = i * 32 + 8 * g + 4 * lhi;                 // channel inside the wave tile
+                const int n = n0 + wn * WTN + nl;
+                f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+                if (OUT_F32) {          // head conv: cout (255) is not a multiple of 4 -> element-wise
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < p.Cout) { be[q] = p.beta[n + q]; if (p.alpha) al[q] = p.alpha[n + q]; }
+                } else if (n < p.Cout) {
+                    be = *reinterpret_cast<const f32x4*>(p.beta + n);
+                    if (p.alpha) al = *reinterpret_cast<const f32x4*>(p.alpha + n);
+                }
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = fmaf(acc[i][j][4 * g + q], al[q], be[q]);
+                    if (p.act == YV3_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
+                    v[q] = t;
+                }
+                *reinterpret_cast<f32x4*>(tile + (j * 32 + l31) * EP + nl) = v;
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int LPR = WTN / 8;                      // lanes per pixel row (8 channels each)
+    constexpr int RPP = 64 / LPR;                     // pixel rows per pass
+#pragma unroll
+    for (int ps = 0; ps < WTM / RPP; ++ps) {
+        const int r = ps * RPP + lane / LPR;
+        const int cg = (lane % LPR) * 8;
+        const int m = m0 + wm * WTM + r;
+        const int n = n0 + wn * WTN + cg;
+        if (m >= p.M || n >= p.Cout) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const long long o = (long long)m * p.Cout + n;
+        if (OUT_F32) {
+            float* yo = (float*)p.y + o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (n + q < p.Cout) yo[q] = v[q];
+        } else {
+            if (p.res) {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {       // planes sum back to the exact fp32 value
+                    const u32x4 q4 = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { v[2 * h] += bf_lo(q4[h]); v[2 * h + 1] += bf_hi(q4[h]); }
+                }
+            }
+            u16* yo = (u16*)p.y + o;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                u32x4 q4;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    q4[h] = pack2_bf16_rn(v[2 * h], v[2 * h + 1]);
+                    v[2 * h] -= bf_lo(q4[h]); v[2 * h + 1] -= bf_hi(q4[h]);
+                }
+                *reinterpret_cast<u32x4*>(yo + pl * p.ys) = q4;
+            }
+        }
+    }
+}
+
+}  // namespace
