@@ -31,10 +31,12 @@ import torch.distributed as dist   # noqa: E402
 
 # MI355X_MICROARCH.md dense MFMA peaks.  f32x3: every fp32 product costs six bf16 MFMAs, so the ceiling
 # for ALGORITHMIC fp32 FLOP/s in that mode is 2500/6 (frac == utilisation of the bf16 matrix pipe).
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "f32h2": 2500.0 / 3}
 DTYPE_NAME = {"f32": "f32 (exact fp32 MFMA)", "bf16": "bf16 (fp32 accumulate)",
-              "f32x3": "f32 via exact 3-way bf16 split: 6 bf16 MFMAs per product, fp32 accumulate"}
-KERNEL_NAME = {"f32": "conv_igemm_f32_kernel", "bf16": "conv_planes_kernel<1>", "f32x3": "conv_planes_kernel<3>"}
+              "f32x3": "f32 via exact 3-way bf16 split: 6 bf16 MFMAs per product, fp32 accumulate",
+              "f32h2": "f32 via 2-way fp16 split (hi+lo): 3 fp16 MFMAs per product, fp32 accumulate"}
+KERNEL_NAME = {"f32": "conv_igemm_f32_kernel", "bf16": "conv_planes_kernel<1>", "f32x3": "conv_planes_kernel<3>",
+               "f32h2": "conv_planes_kernel<2>"}
 
 
 def usable_cores():
@@ -79,8 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=416)
-    ap.add_argument("--dtype", default="f32x3", choices=["f32", "f32x3", "bf16"],
-                    help="conv math mode; f32x3 and f32 both meet the 1e-4 fp32 parity bar (tests/test_gpu_e2e.py)")
+    ap.add_argument("--dtype", default="f32h2", choices=["f32", "f32x3", "f32h2", "bf16"],
+                    help="conv math mode; f32h2, f32x3 and f32 all meet the 1e-4 fp32 parity bar (tests/test_gpu_e2e.py)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra exact-fp32-MFMA measurement")
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--nms", type=float, default=0.4)
@@ -98,7 +100,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    codes = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3}
+    codes = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3, "f32h2": _ffi.F32H2}
 
     # ---- model + data (synthetic SW-1 weights, synthetic scenes; both bit-reproducible)
     stream = synth.weight_stream() if args.weights == "sw1" else synth.dense_weight_stream()
@@ -176,7 +178,7 @@ def main():
     achieved = flops_igemm / (conv_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
     secondary = None
-    if args.dtype == "f32x3" and not args.no_secondary:
+    if args.dtype in ("f32x3", "f32h2") and not args.no_secondary:
         e2, c2, fa2, fi2, _, _ = measure("f32")
         a2 = fi2 / (c2 * 1e-3) / 1e12
         secondary = {"dtype": DTYPE_NAME["f32"], "value": round(B * world * args.steps / e2, 2), "unit": "images/sec",
@@ -217,9 +219,10 @@ def main():
                                                    "from rocprofv3 --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 "
                                                    "calibration in MI355X_MICROARCH.md (confirmed here on decode_kernel); source %s"
                                                    % (n_desc, os.path.basename(tpath)))
-        if args.dtype == "f32x3":
-            out["roofline"]["note"] = ("achieved = algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per "
-                                       "fp32 product, so frac = bf16 matrix-pipe utilisation (%.0f TFLOP/s executed)" % (6 * achieved))
+        if args.dtype in ("f32x3", "f32h2"):
+            nm = {"f32x3": 6, "f32h2": 3}[args.dtype]
+            out["roofline"]["note"] = ("achieved = algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense 16-bit MFMA / %d MFMAs per "
+                                       "fp32 product, so frac = matrix-pipe utilisation (%.0f TFLOP/s executed)" % (nm, nm * achieved))
         if secondary is not None:
             out["exact_fp32_mfma"] = secondary
         if world == 1 and not args.no_cpu_baseline:

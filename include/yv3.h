@@ -39,6 +39,13 @@ extern "C" {
 #define YV3_F32_BF16X3 2         /* 3 bf16 planes = exact split v = p0+p1+p2 of an fp32 value; every fp32
                                     product is evaluated as its 6 leading bf16 partial products with fp32
                                     accumulation: fp32-class error at ~2.7x the fp32-MFMA rate            */
+#define YV3_F32_F16X2 3          /* 2 fp16 planes hi+lo (11+11(+1 sign-carried) mantissa bits; values are
+                                    saturated to +-65504, and magnitudes below 2^-14 keep an ABSOLUTE error
+                                    floor of 2^-25 instead of a relative one); every fp32 product = 3 fp16
+                                    MFMAs (hi*hi, hi*lo, lo*hi; the dropped lo*lo is <= 2^-22 |a*b|), fp32
+                                    accumulation: ~4x fp32 epsilon per product at half the MFMA work of
+                                    YV3_F32_BF16X3.  Callers should scale weights by a power of two so that
+                                    max|w| is O(1) and fold the inverse into alpha (yolo_v3_amd.engine does) */
 
 #define YV3_ACT_LINEAR 0
 #define YV3_ACT_LEAKY  1         /* LeakyReLU(0.1), reference darknet.py:41 */
@@ -62,7 +69,7 @@ int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin,
 int yv3_fold_bn(const float* gamma, const float* bias, const float* mean, const float* var,
                 float eps, float* alpha, float* beta, int channels, void* stream);
 
-/* fp32 [n] <-> NP bf16 planes [NP][n] (np = 1 or 3; 3 is an exact, loss-free split). Layout
+/* fp32 [n] <-> NP planes [NP][n] (np = 1 or 3: bf16, 3 is an exact, loss-free split; np = 2: fp16 hi+lo). Layout
  * conversion helpers for callers that hold fp32 tensors; not used inside the fused network plan. */
 int yv3_split_planes(const float* in, void* out, long long n, int np, void* stream);
 int yv3_merge_planes(const void* in, float* out, long long n, int np, void* stream);
@@ -99,6 +106,9 @@ typedef struct yv3_conv_desc {
     int act;                /* YV3_ACT_*                                                       */
     int dtype;              /* YV3_F32 / YV3_BF16 / YV3_F32_BF16X3: format of x, x2, residual, w */
     int out_dtype;          /* format of y: == dtype, or YV3_F32 (head convs write fp32 logits) */
+    int* flags;             /* optional device int32: bit 0 is OR-ed in when a YV3_F32_F16X2 output had to be
+                               saturated (|value| > 65504), i.e. the fp16 planes cannot represent this
+                               layer -- rerun in YV3_F32_BF16X3 or YV3_F32.  NULL: not reported.           */
 } yv3_conv_desc;
 
 /* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */

@@ -27,7 +27,7 @@ def _input(g, name):
     return torch.from_numpy(synth.images(b, s, int(g[name + "_seed"][0])))
 
 
-@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3])
+@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3, _ffi.F32H2])
 @pytest.mark.parametrize("name", ["dog416", "u416", "u608"])
 def test_forward_and_boxes_vs_reference_golden(golden_dir, net, name, mode):
     """BASELINE configs[0]/[1]-shaped cases, in both fp32 math modes (exact fp32 MFMA and the bf16x3
@@ -94,7 +94,7 @@ def test_decisions_exact_on_identical_detections(net):
         assert torch.equal(r, e)
 
 
-@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3])
+@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3, _ffi.F32H2])
 def test_conv_trunk_vs_oracle_layerwise(net, sw1_stream, mode):
     """Per-layer bring-up check: every conv output of the plan vs the oracle's tap (B=1, 416), in the
     exact-fp32 MFMA mode and in the bf16x3-split mode (same tolerance: both are fp32-class arithmetic)."""
@@ -217,7 +217,7 @@ def test_predict_idiom_matches_oracle_composition(net):
         assert float(preds[i][:, 1].min()) >= 0 and float((preds[i][:, 1] + preds[i][:, 3]).max()) <= im.shape[1] + 1e-3
 
 
-@pytest.mark.parametrize("nc,size,mode", [(20, 320, _ffi.F32X3), (1, 352, _ffi.F32), (20, 320, _ffi.F32)])
+@pytest.mark.parametrize("nc,size,mode", [(20, 320, _ffi.F32X3), (1, 352, _ffi.F32), (20, 320, _ffi.F32), (20, 320, _ffi.F32H2), (1, 352, _ffi.F32H2)])
 def test_other_class_counts_and_sizes(nc, size, mode):
     """Custom-data shapes (reference README: VOC 20 classes, x-wing 1 class): head width 3*(5+nc) is no longer
     255, input size is not 416/608.  Whole net vs the oracle at 1e-4, decisions exact on identical detections."""
@@ -240,3 +240,23 @@ def test_other_class_counts_and_sizes(nc, size, mode):
     check_result_convention(got, exp)
     for a, b in zip(got, exp):
         assert torch.equal(a, b)
+
+
+def test_fp16_plane_overflow_is_reported(sw1_stream):
+    """F32H2 stores activations as fp16 hi+lo planes: a network whose activations leave +-65504 must not
+    silently return saturated results.  Blow up one BN scale -> detect() raises; the other modes still work."""
+    net = load_sw1_net(sw1_stream).cuda()
+    x = torch.from_numpy(synth.images(1, 416, 3)).cuda()
+    net.math_mode = _ffi.F32H2
+    detect(net, x)                                               # sane weights: fine
+    with torch.no_grad():
+        net.feature.mlist[3].bn.weight.mul_(1e6)
+    with pytest.raises(_ffi.Yv3Error, match="fp16 range"):
+        detect(net, x)
+    with pytest.raises(_ffi.Yv3Error, match="fp16 range"):      # asynchronous path: reported by a later forward
+        for _ in range(3):
+            net.forward_cat(x)
+            torch.cuda.synchronize()
+    net.math_mode = _ffi.F32X3                                   # bf16 planes have fp32's exponent range: no error
+    out = net.forward_cat(x)
+    assert out.shape == (1, 10647, 85) and torch.isfinite(out[..., 4:]).all()

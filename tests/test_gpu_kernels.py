@@ -226,18 +226,20 @@ def test_conv_bn_relu_vs_fp64(cin, cout, k, s, B, H, W):
 
 
 @pytest.mark.parametrize("cin,cout,k,s,B,H,W", [c for c in CONV_CASES if c[0] != 3] + [(64, 128, 3, 1, 70, 26, 26), (256, 256, 1, 1, 40, 26, 26)])
-def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W):
-    """Same layers in YV3_F32_BF16X3 mode (bf16-plane tensors, 6 bf16 MFMAs per fp32 product, fp32
-    accumulate).  The split is exact and the dropped partial products are <= 2^-26 of each product, so
-    the SAME fp32 round-off tolerance as the exact-fp32 kernel applies: 2e-5 * max(1,|ref|)."""
+@pytest.mark.parametrize("mode", [_ffi.F32X3, _ffi.F32H2])
+def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W, mode):
+    """Same layers in the two split modes (plane tensors, fp32 accumulate): YV3_F32_BF16X3 (exact 3-way bf16
+    split, 6 MFMAs per product, dropped terms <= 2^-26) and YV3_F32_F16X2 (fp16 hi+lo, 3 MFMAs per product,
+    dropped term <= 2^-22).  Both are fp32-class: the SAME round-off tolerance as the exact-fp32 kernel
+    applies, 2e-5 * max(1,|ref|)."""
     m = _rand_cbr(cin, cout, k, s, seed=cin + cout + k)
     x = torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(1)) * 2 - 0.5
     ho, wo = engine.out_hw(H, W, k, s)
     res = torch.rand(B, cout, ho, wo, generator=torch.Generator().manual_seed(2)) - 0.5
     ref = _ref_cbr(m, x) + res.double()
-    out = _run_mode(m.cuda(), x, _ffi.F32X3, res)
+    out = _run_mode(m.cuda(), x, mode, res)
     assert out.shape == ref.shape
-    assert_close_rel(out, ref, 2e-5, "split conv %s" % ((cin, cout, k, s),))
+    assert_close_rel(out, ref, 2e-5, "split conv mode %d %s" % (mode, (cin, cout, k, s)))
 
 
 @pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(32, 64, 3, 2, 2, 40, 56), (128, 256, 3, 1, 5, 13, 13), (512, 256, 1, 1, 33, 13, 13),

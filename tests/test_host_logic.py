@@ -121,7 +121,7 @@ def test_abi_exports_every_declared_symbol():
     assert b"workspace" in lib.yv3_error_string(-3)
     assert lib.yv3_postproc_cand_bytes(2, 100, 80) >= 2 * 100 * 8 + 2 * 80 * 4
     assert lib.yv3_postproc_nms_workspace_bytes(2, 128, 80) > 2 * 128 * (8 + 16 + 4 + 2) + 2 * 128 * 2 * 8
-    assert ctypes.sizeof(_ffi.ConvDesc) == 7 * 8 + 12 * 4
+    assert ctypes.sizeof(_ffi.ConvDesc) == 7 * 8 + 12 * 4 + 8
 
 
 def test_no_cpu_fallback(sw1_stream):

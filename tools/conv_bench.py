@@ -14,7 +14,7 @@ LAYERS = {  # name: cin, cout, k, stride, H (input), res
 }
 B = int(os.environ.get("BB", "64"))
 iters = int(os.environ.get("ITERS", "10"))
-dt = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3}[os.environ.get("DT", "f32")]
+dt = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3, "f32h2": _ffi.F32H2}[os.environ.get("DT", "f32")]
 tdt = torch.float32
 names = sys.argv[1:] or list(LAYERS)
 torch.cuda.set_device(0)

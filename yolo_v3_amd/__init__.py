@@ -10,7 +10,7 @@ kernels behind the C-ABI in ``include/yv3.h``).
     boxes = detect(net, imgs.cuda())          # same result, fused, one host sync
 """
 from . import arch, synth                      # noqa: F401  (no GPU / extension needed)
-from ._ffi import Yv3Error, F32, BF16          # noqa: F401
+from ._ffi import Yv3Error, F32, BF16, F32X3, F32H2   # noqa: F401
 from .darknet import (YoloNet, Darknet, PreDetectionConvGroup, UpsampleGroup, WeightManager,   # noqa: F401
                       conv_bn_relu, res_layer)
 from .yololayer import YoloLayer               # noqa: F401

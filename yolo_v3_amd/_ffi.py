@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YV3_LIB") or os.path.join(_HERE, "libyv3.so")     # YV3_LIB: kernel-tuning builds only
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, F32H2 = 0, 1, 2, 3
 ACT_LINEAR, ACT_LEAKY = 0, 1
 PP_EVAL, PP_PROB = 1, 2
 
@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
                 ("residual", c_void_p), ("y", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("cin", c_int), ("cin_up", c_int),
                 ("cout", c_int), ("cout_pad", c_int), ("k", c_int), ("stride", c_int), ("act", c_int),
-                ("dtype", c_int), ("out_dtype", c_int)]
+                ("dtype", c_int), ("out_dtype", c_int), ("flags", c_void_p)]
 
 
 _SIGNATURES = {

@@ -38,10 +38,10 @@ extern "C" int yv3_conv2d(const yv3_conv_desc* d, void* stream) {
         if (d->out_dtype != YV3_F32) return YV3_EDTYPE;
         return yv3_conv2d_f32(d, (hipStream_t)stream);
     }
-    if (d->dtype == YV3_F32_BF16X3 || d->dtype == YV3_BF16) {
+    if (d->dtype == YV3_F32_BF16X3 || d->dtype == YV3_BF16 || d->dtype == YV3_F32_F16X2) {
         if (d->out_dtype != YV3_F32 && d->out_dtype != d->dtype) return YV3_EDTYPE;
         if (d->cin % 32) return YV3_ESHAPE;
-        return yv3_conv2d_planes(d, d->dtype == YV3_BF16 ? 1 : 3, (hipStream_t)stream);
+        return yv3_conv2d_planes(d, d->dtype == YV3_BF16 ? 1 : d->dtype == YV3_F32_F16X2 ? 2 : 3, (hipStream_t)stream);
     }
     return YV3_EDTYPE;
 }

@@ -12,7 +12,8 @@
 
 namespace {
 
-// NP = 0: fp32 NHWC output; NP = 1 / 3: bf16 planes [NP][B,H,W,32] (3 = exact split of the fp32 value)
+// NP = 0: fp32 NHWC output; NP = 1 / 3: bf16 planes [NP][B,H,W,32] (3 = exact split of the fp32 value);
+// NP = 2: fp16 planes (hi + lo)
 template <int NP>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                    const float* __restrict__ alpha, const float* __restrict__ beta,
@@ -73,9 +74,16 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
                 float v0 = tile[(e >> 5) * 33 + (e & 31)], v1 = tile[(e >> 5) * 33 + (e & 31) + 1];
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
-                    const u16 h0 = yv3_f2bf(v0), h1 = yv3_f2bf(v1);
+                    u16 h0, h1;
+                    if constexpr (NP == 2) {
+                        const _Float16 a = (_Float16)v0, b = (_Float16)v1;       // activations of layer 0 are O(1): no saturation needed
+                        h0 = __builtin_bit_cast(unsigned short, a); h1 = __builtin_bit_cast(unsigned short, b);
+                        v0 -= (float)a; v1 -= (float)b;
+                    } else {
+                        h0 = yv3_f2bf(v0); h1 = yv3_f2bf(v1);
+                        v0 -= yv3_bf2f(h0); v1 -= yv3_bf2f(h1);
+                    }
                     *reinterpret_cast<unsigned*>(y + pl * plane_stride + obase + e) = (unsigned)h0 | ((unsigned)h1 << 16);
-                    v0 -= yv3_bf2f(h0); v1 -= yv3_bf2f(h1);
                 }
             }
         }
@@ -97,6 +105,8 @@ extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const fl
         hipLaunchKernelGGL(conv0_kernel<1>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else if (out_dtype == YV3_F32_BF16X3)
         hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
+    else if (out_dtype == YV3_F32_F16X2)
+        hipLaunchKernelGGL(conv0_kernel<2>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else
         return YV3_EDTYPE;
     YV3_CHECK_LAUNCH();

@@ -241,15 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                 f32x16 c = acc[i][j];
                 const bf16x8v* wf = &frag[ks][i * NP];
                 const bf16x8v* xf = &frag[ks][NT * NP + j * NP];
-                if constexpr (NP == 3) {
-                    // smallest partial products first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[1], c, 0, 0, 0);
-                }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0], c, 0, 0, 0);
+                c = mfma_unit<NP>(wf, xf, c);
                 acc[i][j] = c;
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -310,9 +302,9 @@ __global__ void pack_weight_planes_kernel(const float* __restrict__ in, u16* __r
     const long long base = (((long long)(n / tb) * nk + kidx / PBK) * NP) * (long long)(tb * PBK) + r * PBK + slot * 8 + (ke & 7);
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
-        const u16 h = yv3_f2bf(v);
+        const u16 h = PlaneOps<NP>::cvt(v);
         out[base + (long long)pl * tb * PBK] = h;
-        v -= yv3_bf2f(h);
+        v -= PlaneOps<NP>::back(h);
     }
 }
 
@@ -324,9 +316,9 @@ __global__ void split_planes_kernel(const float* __restrict__ in, u16* __restric
     float v = in[i];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
-        const u16 h = yv3_f2bf(v);
+        const u16 h = PlaneOps<NP>::cvt(v);
         out[i + pl * n] = h;
-        v -= yv3_bf2f(h);
+        v -= PlaneOps<NP>::back(h);
     }
 }
 
@@ -336,7 +328,7 @@ __global__ void merge_planes_kernel(const u16* __restrict__ in, float* __restric
     if (i >= n) return;
     float v = 0.f;
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl) v += yv3_bf2f(in[i + pl * n]);
+    for (int pl = 0; pl < NP; ++pl) v += PlaneOps<NP>::back(in[i + pl * n]);
     out[i] = v;
 }
 
@@ -347,28 +339,31 @@ int yv3_pack_weight_planes(const float* w_oihw, void* w_packed, int cout, int ci
     const int tb = cout_pad < 128 ? cout_pad : 128;
     if (cout_pad % tb) return YV3_ESHAPE;
     const dim3 grid(yv3_ceil_div(total, 256));
-    if (np == 3) hipLaunchKernelGGL(pack_weight_planes_kernel<3>, grid, dim3(256), 0, s, w_oihw, (u16*)w_packed, cout, cin, k, tb, total);
-    else         hipLaunchKernelGGL(pack_weight_planes_kernel<1>, grid, dim3(256), 0, s, w_oihw, (u16*)w_packed, cout, cin, k, tb, total);
+    if (np == 3)      hipLaunchKernelGGL(pack_weight_planes_kernel<3>, grid, dim3(256), 0, s, w_oihw, (u16*)w_packed, cout, cin, k, tb, total);
+    else if (np == 2) hipLaunchKernelGGL(pack_weight_planes_kernel<2>, grid, dim3(256), 0, s, w_oihw, (u16*)w_packed, cout, cin, k, tb, total);
+    else              hipLaunchKernelGGL(pack_weight_planes_kernel<1>, grid, dim3(256), 0, s, w_oihw, (u16*)w_packed, cout, cin, k, tb, total);
     YV3_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int yv3_split_planes(const float* in, void* out, long long n, int np, void* stream) {
-    if (!in || !out || n < 0 || (np != 1 && np != 3)) return YV3_EINVAL;
+    if (!in || !out || n < 0 || np < 1 || np > 3) return YV3_EINVAL;
     if (n == 0) return 0;
     const dim3 grid(yv3_ceil_div(n, 256));
-    if (np == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, in, (u16*)out, n);
-    else         hipLaunchKernelGGL(split_planes_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, in, (u16*)out, n);
+    if (np == 3)      hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, in, (u16*)out, n);
+    else if (np == 2) hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, in, (u16*)out, n);
+    else              hipLaunchKernelGGL(split_planes_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, in, (u16*)out, n);
     YV3_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int yv3_merge_planes(const void* in, float* out, long long n, int np, void* stream) {
-    if (!in || !out || n < 0 || (np != 1 && np != 3)) return YV3_EINVAL;
+    if (!in || !out || n < 0 || np < 1 || np > 3) return YV3_EINVAL;
     if (n == 0) return 0;
     const dim3 grid(yv3_ceil_div(n, 256));
-    if (np == 3) hipLaunchKernelGGL(merge_planes_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)in, out, n);
-    else         hipLaunchKernelGGL(merge_planes_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)in, out, n);
+    if (np == 3)      hipLaunchKernelGGL(merge_planes_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)in, out, n);
+    else if (np == 2) hipLaunchKernelGGL(merge_planes_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)in, out, n);
+    else              hipLaunchKernelGGL(merge_planes_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)in, out, n);
     YV3_CHECK_LAUNCH();
     return 0;
 }
@@ -380,7 +375,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     p.x = (const u16*)d->x; p.x2 = (const u16*)d->x2; p.w = (const u16*)d->w;
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const u16*)d->residual; p.y = d->y;
     p.H = d->H; p.W = d->W; p.Cin = d->cin; p.Cup = d->cin_up; p.Cout = d->cout;
-    p.stride = d->stride; p.act = d->act;
+    p.stride = d->stride; p.act = d->act; p.flags = d->flags;
     const int pad = (d->k - 1) / 2;
     p.Ho = (d->H + 2 * pad - d->k) / d->stride + 1;
     p.Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
@@ -409,8 +404,9 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
         if (rc != -100) return rc;
     }
-#define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s) \
-                                                   : launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s))
+#define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s) : \
+                                         np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, s) : \
+                                                   launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s))
     if (npad % 128 == 0) {
         // 256x128 tiles (8 waves, 144 KB LDS) when they still give every CU >= 2 rounds of work,
         // else 128x128 tiles (8 waves of 32x64) for finer granularity on the 13x13 / 26x26 layers

@@ -17,6 +17,7 @@ struct ConvParamsP {
     int nk;                     // K / PBK
     int ntiles;
     int tb;                     // rows per packed weight tile
+    int* flags;                 // optional: bit 0 <- an fp16-plane output was saturated
 };
 
 namespace {
@@ -39,13 +40,57 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-__device__ inline unsigned pack2_bf16_rn(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+
+// Element type of the planes and the MFMA that consumes them.
+//   NP = 1, 3: bf16 (v_cvt_pk_bf16_f32 RN, v_mfma_f32_32x32x16_bf16)
+//   NP = 2   : fp16 (v_cvt_f16_f32 RN after saturating to +-65504, v_mfma_f32_32x32x16_f16)
+template <int NP> struct PlaneOps {
+    static __device__ inline unsigned pack2(float lo, float hi) {
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
+    static __device__ inline float lo(unsigned q) { return __uint_as_float(q << 16); }
+    static __device__ inline float hi(unsigned q) { return __uint_as_float(q & 0xffff0000u); }
+    static __device__ inline f32x16 mfma(bf16x8v a, bf16x8v b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __host__ __device__ inline u16 cvt(float v) { return yv3_f2bf(v); }
+    static __host__ __device__ inline float back(u16 h) { return yv3_bf2f(h); }
+};
+template <> struct PlaneOps<2> {
+    static __device__ inline _Float16 sat(float v) { return (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }
+    static __device__ inline unsigned pack2(float lo, float hi) {
+        return (unsigned)__builtin_bit_cast(unsigned short, sat(lo)) | ((unsigned)__builtin_bit_cast(unsigned short, sat(hi)) << 16);
+    }
+    static __device__ inline float lo(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu)); }
+    static __device__ inline float hi(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16)); }
+    static __device__ inline f32x16 mfma(bf16x8v a, bf16x8v b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+    }
+    static __device__ inline u16 cvt(float v) { return __builtin_bit_cast(unsigned short, sat(v)); }
+    static __device__ inline float back(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
+};
+
+// One "unit" = all partial products of one (weight tile, pixel tile) pair for one 16-deep k-step.
+//   NP = 3 (exact bf16 split, 8+8+8 bits): the six products of weight >= 2^-16, smallest first
+//   NP = 2 (fp16 split, 11+11(+1) bits)  : w1*x0, w0*x1, w0*x0 (the dropped w1*x1 is <= 2^-22 |w*x|)
+//   NP = 1                               : w0*x0
+template <int NP>
+__device__ inline f32x16 mfma_unit(const bf16x8v* wf, const bf16x8v* xf, f32x16 c) {
+    if constexpr (NP == 3) {
+        c = PlaneOps<3>::mfma(wf[2], xf[0], c);
+        c = PlaneOps<3>::mfma(wf[0], xf[2], c);
+        c = PlaneOps<3>::mfma(wf[1], xf[1], c);
+        c = PlaneOps<3>::mfma(wf[1], xf[0], c);
+        c = PlaneOps<3>::mfma(wf[0], xf[1], c);
+    } else if constexpr (NP == 2) {
+        c = PlaneOps<2>::mfma(wf[1], xf[0], c);
+        c = PlaneOps<2>::mfma(wf[0], xf[1], c);
+    }
+    return PlaneOps<NP>::mfma(wf[0], xf[0], c);
 }
-__device__ inline float bf_lo(unsigned q) { return __uint_as_float(q << 16); }
-__device__ inline float bf_hi(unsigned q) { return __uint_as_float(q & 0xffff0000u); }
 
 // bank-conflict swizzle for 64-byte rows read with ds_read_b128: four rows share a 256-byte bank row
 __device__ __host__ inline int swz(int row) { return (row >> 2) & (SLOTS - 1); }
@@ -102,6 +147,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool ovf = false;
     constexpr int LPR = WTN / 8;                      // lanes per pixel row (8 channels each)
     constexpr int RPP = 64 / LPR;                     // pixel rows per pass
 #pragma unroll
@@ -126,21 +172,28 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
                 for (int pl = 0; pl < NP; ++pl) {       // planes sum back to the exact fp32 value
                     const u32x4 q4 = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) { v[2 * h] += bf_lo(q4[h]); v[2 * h + 1] += bf_hi(q4[h]); }
+                    for (int h = 0; h < 4; ++h) { v[2 * h] += PlaneOps<NP>::lo(q4[h]); v[2 * h + 1] += PlaneOps<NP>::hi(q4[h]); }
                 }
             }
             u16* yo = (u16*)p.y + o;
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ovf |= !(__builtin_fabsf(v[q]) <= 65504.f);
+            }
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 u32x4 q4;
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    q4[h] = pack2_bf16_rn(v[2 * h], v[2 * h + 1]);
-                    v[2 * h] -= bf_lo(q4[h]); v[2 * h + 1] -= bf_hi(q4[h]);
+                    q4[h] = PlaneOps<NP>::pack2(v[2 * h], v[2 * h + 1]);
+                    v[2 * h] -= PlaneOps<NP>::lo(q4[h]); v[2 * h + 1] -= PlaneOps<NP>::hi(q4[h]);
                 }
                 *reinterpret_cast<u32x4*>(yo + pl * p.ys) = q4;
             }
         }
+    }
+    if constexpr (NP == 2) {
+        if (p.flags && __any(ovf) && lane == 0) atomicOr(p.flags, 1);
     }
 }
 

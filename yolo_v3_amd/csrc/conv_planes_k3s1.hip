@@ -214,14 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_k3s1_kernel(const Co
                     }
                     const bf16x8v* wf = &frag[ks][i * NP];
                     f32x16 c = acc[i][j];
-                    if constexpr (NP == 3) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[1], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0], c, 0, 0, 0);
+                    c = mfma_unit<NP>(wf, xf, c);
                     acc[i][j] = c;
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -250,7 +243,7 @@ int launch_k3s1(const ConvParamsP& p, hipStream_t s) {
 int yv3_conv2d_planes_k3s1(const ConvParamsP* pp, int np, int npad, long long M, hipStream_t s) {
     ConvParamsP p = *pp;
     if (p.Cin % PBK) return -100;
-#define YV3_K3(BM_, BN_, WM_, WN_) (np == 3 ? launch_k3s1<3, BM_, BN_, WM_, WN_>(p, s) : launch_k3s1<1, BM_, BN_, WM_, WN_>(p, s))
+#define YV3_K3(BM_, BN_, WM_, WN_) (np == 3 ? launch_k3s1<3, BM_, BN_, WM_, WN_>(p, s) : np == 2 ? launch_k3s1<2, BM_, BN_, WM_, WN_>(p, s) : launch_k3s1<1, BM_, BN_, WM_, WN_>(p, s))
     if (npad % 128 == 0) {
         const long long blocks256 = ((M + 255) / 256) * (npad / 128);
         p.ntiles = npad / 128;

@@ -46,6 +46,7 @@ extern "C" int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cou
     hipStream_t s = (hipStream_t)stream;
     if (dtype == YV3_F32_BF16X3) return yv3_pack_weight_planes(w_oihw, w_packed, cout, cin, k, cout_pad, 3, s);
     if (dtype == YV3_BF16) return yv3_pack_weight_planes(w_oihw, w_packed, cout, cin, k, cout_pad, 1, s);
+    if (dtype == YV3_F32_F16X2) return yv3_pack_weight_planes(w_oihw, w_packed, cout, cin, k, cout_pad, 2, s);
     if (dtype == YV3_F32)
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_packed, cout, cin, k, total);
     else

@@ -26,6 +26,7 @@ class Detector:
         self.engine = net.engine(dtype)
         self.engine.ensure_packed()
         self.device = self.engine.device
+        self._generation = self.engine.generation
         with torch.cuda.device(self.device):
             self.plan = self.engine.plan(batch, height, width)
             self.dets = torch.empty((batch, self.plan.N, self.plan.attrib), device=self.device, dtype=torch.float32)
@@ -65,6 +66,10 @@ class Detector:
             raise _ffi.Yv3Error("Detector was built for %s, got %s" % (self.shape, tuple(x.shape)))
         with torch.cuda.device(self.device):
             self.engine.ensure_packed()
+            if self.engine.generation != self._generation:      # parameters changed: packed weights / plan were rebuilt
+                self._generation = self.engine.generation
+                self.plan = self.engine.plan(self.shape[0], self.shape[2], self.shape[3])
+                self._graph = None
             if self._want_graph:
                 if self._graph is None:
                     self._capture(x)
@@ -76,7 +81,9 @@ class Detector:
 
     def __call__(self, imgs):
         boxes, counts = self.run_device(imgs)
-        return self.pp.to_list(boxes, counts.cpu())          # the single D2H sync
+        host = torch.cat((counts, self.plan.flags)).cpu()    # the single D2H sync: counts + saturation flag
+        self.engine.raise_if_overflowed(self.plan, int(host[-1]))
+        return self.pp.to_list(boxes, host[:-1])
 
 
 def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True):

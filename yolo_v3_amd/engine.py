@@ -18,10 +18,12 @@ import ctypes
 import torch
 
 from . import _ffi, arch
-from ._ffi import ConvDesc, F32, BF16, F32X3, ACT_LEAKY, ACT_LINEAR
+import math
 
-_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F32X3: torch.bfloat16}    # element type of activation storage
-PLANES = {F32: 0, BF16: 1, F32X3: 3}       # 0: plain fp32 NHWC tensor; n > 0: n bf16 planes [n][B,H,W,C]
+from ._ffi import ConvDesc, F32, BF16, F32X3, F32H2, ACT_LEAKY, ACT_LINEAR
+
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F32X3: torch.bfloat16, F32H2: torch.float16}   # element type of activation storage
+PLANES = {F32: 0, BF16: 1, F32X3: 3, F32H2: 2}   # 0: plain fp32 NHWC tensor; n > 0: n 16-bit planes [n][B,H,W,C]
 
 
 def alloc_act(B, h, w, c, dtype, device):
@@ -37,7 +39,7 @@ def to_planes(x_nhwc_f32, dtype):
     if np_ == 0:
         return x_nhwc_f32.float().contiguous()
     x = x_nhwc_f32.float().contiguous()
-    out = torch.empty((np_,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((np_,) + tuple(x.shape), device=x.device, dtype=_TORCH_DTYPE[dtype])
     _ffi.check(_ffi.lib().yv3_split_planes(x.data_ptr(), out.data_ptr(), x.numel(), np_, _ffi.stream_ptr()), "yv3_split_planes")
     return out
 
@@ -89,6 +91,13 @@ def pack_conv(module, spec, dtype):
     else:
         alpha = None
         beta = bias.detach().float().contiguous().clone()
+    if dtype == F32H2 and spec.cin != 3:
+        # fp16 planes keep a relative precision of 2^-23 only above 2^-14 * 2^11: bring the weights to O(1)
+        # with an exact power-of-two scale and fold its inverse into the epilogue scale (also exact)
+        wmax = float(w32.abs().max())
+        e = -math.floor(math.log2(wmax)) if wmax > 0 else 0
+        w32 = w32 * (2.0 ** e)
+        alpha = (alpha if alpha is not None else torch.ones(spec.cout, device=dev, dtype=torch.float32)) * (2.0 ** -e)
     if spec.cin == 3:
         # first layer: direct-conv kernel wants [cin][kh][kw][cout] fp32
         return PackedConv(spec, w32.permute(1, 2, 3, 0).contiguous(), alpha, beta, spec.cout)
@@ -100,7 +109,7 @@ def pack_conv(module, spec, dtype):
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
 
-def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None):
+def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None):
     sp = pc.spec
     d = ConvDesc()
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
@@ -112,6 +121,7 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
     d.act = ACT_LEAKY if sp.bn else ACT_LINEAR
     d.dtype = dtype
     d.out_dtype = dtype if out_dtype is None else out_dtype
+    d.flags = _ptr(flags)
     return d
 
 
@@ -133,6 +143,10 @@ class Plan:
         attrib = 5 + nc
         keep = []            # every buffer the descriptors point to
         descs = []
+        # sticky status word written by the kernels (bit 0: an fp16-plane output was saturated) + its host mirror
+        self.flags = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.flags_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.flags_event = None
         self.layer_out = {}  # conv name -> (buffer, (h, w, c)) for bring-up / per-layer parity tests
 
         def buf(h, w, c, dtype=dt):
@@ -144,7 +158,7 @@ class Plan:
             pc = packed[i]
             ho, wo = out_hw(h, w, pc.spec.k, pc.spec.stride)
             y = buf(ho, wo, pc.spec.cout, dt if out_dtype is None else out_dtype)
-            descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype))
+            descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags))
             self.layer_out[pc.spec.name] = y
             return y, ho, wo
 
@@ -223,6 +237,7 @@ class Engine:
         self.device = None
         self._sig = None
         self._plans = {}
+        self.generation = 0
 
     # -- weights
     def _signature(self):
@@ -247,6 +262,7 @@ class Engine:
             self.packed = [pack_conv(self.net.get_submodule(sp.name), sp, self.dtype) for sp in self.specs]
         self._sig = sig
         self._plans = {}
+        self.generation += 1          # holders of a Plan (Detector) must rebuild: descriptors point into `packed`
 
     # -- plans
     def plan(self, B, H, W):
@@ -282,15 +298,36 @@ class Engine:
             x = x.float().contiguous()
         return x
 
+    OVERFLOW_MSG = ("an activation exceeded the fp16 range (|v| > 65504) and was saturated: math mode F32H2 cannot "
+                    "represent this network/input; set net.math_mode = yolo_v3_amd.F32X3 (or F32) and rerun")
+
+    def raise_if_overflowed(self, plan, flag_value):
+        """Turn the kernels' sticky saturation flag into an error (and clear it)."""
+        if flag_value:
+            plan.flags.zero_()
+            plan.flags_host.zero_()
+            plan.flags_event = None
+            raise _ffi.Yv3Error(self.OVERFLOW_MSG)
+
     def forward(self, x, dets=None):
-        """x: [B,3,H,W] fp32 on the GPU -> detections [B, N, 5+C] (cx,cy,w,h,conf,cls...)."""
+        """x: [B,3,H,W] fp32 on the GPU -> detections [B, N, 5+C] (cx,cy,w,h,conf,cls...).
+
+        Stays asynchronous.  In F32H2 mode the saturation flag of a call is copied to pinned host memory behind
+        it and examined (without blocking) at the start of the NEXT call on the same plan; `Detector` / `detect`
+        check it synchronously together with the box counts."""
         x = self.prepare_input(x)
         with torch.cuda.device(x.device):
             self.ensure_packed()
             B, _, H, W = x.shape
             plan = self.plan(B, H, W)
+            if self.dtype == F32H2 and plan.flags_event is not None and plan.flags_event.query():
+                self.raise_if_overflowed(plan, int(plan.flags_host[0]))
             if dets is None:
                 dets = torch.empty((B, plan.N, plan.attrib), device=x.device, dtype=torch.float32)
             self.run_convs(plan, x)
             self.run_decode(plan, dets)
+            if self.dtype == F32H2:
+                plan.flags_host.copy_(plan.flags, non_blocking=True)
+                plan.flags_event = torch.cuda.Event()
+                plan.flags_event.record()
         return dets, plan
