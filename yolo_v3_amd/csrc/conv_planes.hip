@@ -25,7 +25,19 @@
 
 namespace {
 
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32>
+#ifndef YV3_PP_DMA
+#define YV3_PP_DMA 1
+#endif
+#ifndef YV3_PP_GRP
+#define YV3_PP_GRP(wid) ((wid) >> 2)
+#endif
+
+// PP ("ping-pong"): the 8 waves of the workgroup form two groups of four (one wave per SIMD each) that run
+// half a chunk out of phase: while one group issues a chunk's 24 MFMAs from registers, the other reads its
+// fragments of the next chunk from LDS and issues its share of the DMA, then they swap at an s_barrier.
+// Each SIMD's matrix pipe is thereby fed by one wave while its partner wave loads, instead of both
+// waves stalling on LDS / DMA / barrier at the same time.
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvParamsP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile: WTM pixels x WTN channels
@@ -160,6 +172,79 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                frag[ks][f] = *reinterpret_cast<const bf16x8v*>(st + x_row + fslot + (g / NP) * 32 * ROWB + (g % NP) * A_PLANE); }
     };
 
+    if constexpr (PP) {
+        static_assert(!PP || (NW == 8 && NSTAGE >= 3 && NP == 2), "ping-pong: 8 waves, 3-deep ring, fp16x2 planes");
+        const int grp = YV3_PP_GRP(wid);
+        if (D <= p.nk) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();       // chunk 0 has landed
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();                           // group 1 runs one segment behind
+        int cur = 0, nxt = D % NSTAGE;
+        for (int kc = 0; kc < p.nk; ++kc) {
+            // ---- load segment: fragments of chunk kc -> registers, DMA of chunk kc+D -> the stage chunk kc-1 used
+            st = lds + cur * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) read_frag(ks, f);
+            const bool more = kc + D < p.nk;
+#if YV3_PP_DMA == 0
+            if (more) {
+                dma_prepare(kc + D, nxt);
+#pragma unroll
+                for (int g = 0; g < G; ++g) dma_piece(g);
+                wait_vmcnt<(D - 1) * G>();                                    // my pieces of chunk kc+1 have landed
+            } else {
+                wait_vmcnt<0>();
+            }
+#else
+            // addresses now (VALU, off the matrix pipe's critical path); the pieces go out between the MFMAs of
+            // the compute segment.  My pieces of chunk kc+1 (issued D-1 compute segments ago) must have landed.
+            if (more) dma_prepare(kc + D, nxt);
+            if (kc + D - 1 < p.nk) wait_vmcnt<(D - 2) * G>(); else wait_vmcnt<0>();
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- compute segment: registers only
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if constexpr (NP == 2) {                                       // rotate over the accumulators: no back-to-back RAW
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) {
+                            const int i = u / MT, j = u % MT;
+                            const bf16x8v* wf = &frag[ks][i * NP];
+                            const bf16x8v* xf = &frag[ks][NT * NP + j * NP];
+                            acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
+#if YV3_PP_DMA != 0
+                            {   // one DMA piece after every (24 / G)-th MFMA
+                                constexpr int TOT = KS * 3 * NU;
+                                const int mi = (ks * 3 + t) * NU + u;
+                                if (more && (mi * G) / TOT != ((mi + 1) * G) / TOT) dma_piece((mi * G) / TOT);
+                            }
+#endif
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int i = u / MT, j = u % MT;
+                        acc[i][j] = mfma_unit<NP>(&frag[ks][i * NP], &frag[ks][NT * NP + j * NP], acc[i][j]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(grp == 1 && kc + 1 == p.nk)) __builtin_amdgcn_s_barrier();  // both groups pass 2*nk + 1 barriers
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+        }
+        // group 0 starts its epilogue while group 1 still computes (group 1 reads no LDS in its last segment and
+        // the epilogue's LDS tiles are per wave)
+        epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
+        return;
+    }
 #ifdef YV3_TIMELINE
     unsigned long long tl_wait = 0, tl_bar = 0, tl_body = 0, tl_prev = 0, tl_dma = 0;
 #endif
@@ -268,8 +353,12 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, hipStream
     const size_t pipe = (size_t)NSTAGE * NP * (BM + BN) * ROWB;
     const size_t epi = (size_t)WN * BM * (BN / WN + 4) * 4;   // WM*WN waves x (BM/WM) rows x (BN/WN + 4) floats
     const size_t lds = pipe > epi ? pipe : epi;
-#define YV3_LAUNCH(K3_, DUAL_, OF_) \
-    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_>), grid, block, lds, s, p)
+    static const bool use_pp = getenv("YV3_NO_PP") == nullptr;     // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
+#define YV3_LAUNCH(K3_, DUAL_, OF_) do { \
+    if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3) { \
+        if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, p); break; } \
+    } \
+    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_>), grid, block, lds, s, p); } while (0)
     if (out_f32) {
         if (k3 || dual) return YV3_ESHAPE;                   // fp32 outputs are the 1x1 head convs
         YV3_LAUNCH(false, false, true);

@@ -100,7 +100,7 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 
 // ---- epilogue shared by both kernels: acc[NT][MT] of the wave tile -> BN/activation -> LDS transpose ->
 // residual add -> output planes (or fp32).  `lds` must have NW * WTM * (WTN+4) * 4 bytes available.
-template <int NP, int BM, int BN, int WM, int WN, bool OUT_F32>
+template <int NP, int BM, int BN, int WM, int WN, bool OUT_F32, bool SYNC = true>
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], const ConvParamsP& p,
                                                unsigned char* lds, int m0, int n0, int wid, int lane) {
     constexpr int NW = WM * WN;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     // of one pixel: residual planes are read and output planes written as full 16-byte-per-lane rows.
     constexpr int EP = WTN + 4;                       // floats per tile row (+4: conflict-free ds_write_b128)
     // (launch_cfg sizes the dynamic LDS as max(pipeline, NW * WTM * EP * 4))
-    __syncthreads();                                  // every wave is done with the last stage
+    if constexpr (SYNC) __syncthreads();              // every wave is done with the last stage
     float* tile = reinterpret_cast<float*>(lds) + wid * (WTM * EP);
 #pragma unroll
     for (int j = 0; j < MT; ++j)
