@@ -53,7 +53,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     static_assert(AROWS % RPG == 0 && BROWS <= RPG && MT >= 1 && NT >= 1, "tile/wave layout");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef YV3_TIMELINE
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memtime();
+#endif
 
+    if (PP && p.stagger && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const int bid = yv3_xcd_remap(blockIdx.x, gridDim.x);
     const int n0 = (bid % p.ntiles) * BN;
     const int m0 = (bid / p.ntiles) * BM;
@@ -175,18 +181,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     if constexpr (PP) {
         static_assert(!PP || (NW == 8 && NSTAGE >= 3 && NP == 2), "ping-pong: 8 waves, 3-deep ring, fp16x2 planes");
         const int grp = YV3_PP_GRP(wid);
+        // 32x64 wave tiles (128x128 workgroup tile): the compute segment is only 12 MFMAs per k-step, so the second
+        // k-step's fragments are fetched under the first k-step's MFMAs; measured +5 % there, -5 % on 64x64 wave tiles
+        constexpr bool SPLIT = MT == 1;
         if (D <= p.nk) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();       // chunk 0 has landed
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();                           // group 1 runs one segment behind
+#ifdef YV3_TIMELINE
+        const unsigned long long tl_loop0 = __builtin_amdgcn_s_memtime();
+        unsigned long long tl_load = 0, tl_b1 = 0, tl_comp = 0, tl_b2 = 0, tl_t = tl_loop0;
+        unsigned long long tl_l1 = 0, tl_l2 = 0, tl_l3 = 0;
+#define TL_MARK(acc_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - tl_t; tl_t = t_; } while (0)
+#else
+#define TL_MARK(acc_) do {} while (0)
+#endif
         int cur = 0, nxt = D % NSTAGE;
         for (int kc = 0; kc < p.nk; ++kc) {
             // ---- load segment: fragments of chunk kc -> registers, DMA of chunk kc+D -> the stage chunk kc-1 used
             st = lds + cur * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < (SPLIT ? 1 : KS); ++ks)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) read_frag(ks, f);
             const bool more = kc + D < p.nk;
+#ifdef YV3_TIMELINE
+            __builtin_amdgcn_sched_barrier(0);
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_l1 += t_ - tl_t; }
+#endif
 #if YV3_PP_DMA == 0
             if (more) {
                 dma_prepare(kc + D, nxt);
@@ -200,15 +221,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
             // addresses now (VALU, off the matrix pipe's critical path); the pieces go out between the MFMAs of
             // the compute segment.  My pieces of chunk kc+1 (issued D-1 compute segments ago) must have landed.
             if (more) dma_prepare(kc + D, nxt);
+#ifdef YV3_TIMELINE
+            __builtin_amdgcn_sched_barrier(0);
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_l2 += t_ - tl_t; }
+#endif
             if (kc + D - 1 < p.nk) wait_vmcnt<(D - 2) * G>(); else wait_vmcnt<0>();
+#ifdef YV3_TIMELINE
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_l3 += t_ - tl_t; }
+#endif
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            TL_MARK(tl_load);
             __builtin_amdgcn_s_barrier();
+            TL_MARK(tl_b1);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- compute segment: registers only
+            // ---- compute segment: registers only (SPLIT: plus the second k-step's fragment reads)
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) read_frag(ks, f);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                if (SPLIT && ks == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (NP == 2) {                                       // rotate over the accumulators: no back-to-back RAW
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
@@ -235,14 +272,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            TL_MARK(tl_comp);
             if (!(grp == 1 && kc + 1 == p.nk)) __builtin_amdgcn_s_barrier();  // both groups pass 2*nk + 1 barriers
+            TL_MARK(tl_b2);
             __builtin_amdgcn_sched_barrier(0);
             cur = cur + 1 == NSTAGE ? 0 : cur + 1;
             nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
         }
         // group 0 starts its epilogue while group 1 still computes (group 1 reads no LDS in its last segment and
         // the epilogue's LDS tiles are per wave)
+#ifdef YV3_TIMELINE
+        const unsigned long long tl_loop1 = __builtin_amdgcn_s_memtime();
+#endif
         epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
+#ifdef YV3_TIMELINE
+        const unsigned long long tl_epi = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl_drain = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 300 && lane == 0 && p.alpha) {     // debug build only: cycle split of one block -> alpha[0..]
+            float* dbg = const_cast<float*>(p.alpha) + wid * 8;
+            dbg[0] = (float)(tl_loop0 - tl_entry); dbg[1] = (float)tl_load; dbg[2] = (float)tl_b1; dbg[3] = (float)tl_comp;
+            dbg[4] = (float)tl_b2; dbg[5] = (float)(tl_epi - tl_loop1); dbg[6] = (float)(tl_drain - tl_epi); dbg[7] = (float)(tl_drain - tl_entry);
+            dbg[64] = (float)tl_l1; dbg[65] = (float)tl_l2; dbg[66] = (float)tl_l3;
+        }
+#endif
         return;
     }
 #ifdef YV3_TIMELINE
@@ -465,6 +518,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const u16*)d->residual; p.y = d->y;
     p.H = d->H; p.W = d->W; p.Cin = d->cin; p.Cup = d->cin_up; p.Cout = d->cout;
     p.stride = d->stride; p.act = d->act; p.flags = d->flags;
+    { const char* e = getenv("YV3_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     const int pad = (d->k - 1) / 2;
     p.Ho = (d->H + 2 * pad - d->k) / d->stride + 1;
     p.Wo = (d->W + 2 * pad - d->k) / d->stride + 1;

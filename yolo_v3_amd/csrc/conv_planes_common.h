@@ -16,6 +16,7 @@ struct ConvParamsP {
     int Ho, Wo, M, K;
     int nk;                     // K / PBK
     int ntiles;
+    int stagger;                // first-round workgroups with (blockIdx>>3)&1 sleep stagger*1024 cycles before starting
     int tb;                     // rows per packed weight tile
     int* flags;                 // optional: bit 0 <- an fp16-plane output was saturated
 };
@@ -61,8 +62,17 @@ template <int NP> struct PlaneOps {
 };
 template <> struct PlaneOps<2> {
     static __device__ inline _Float16 sat(float v) { return (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }
-    static __device__ inline unsigned pack2(float lo, float hi) {
-        return (unsigned)__builtin_bit_cast(unsigned short, sat(lo)) | ((unsigned)__builtin_bit_cast(unsigned short, sat(hi)) << 16);
+    static __device__ inline unsigned pack2(float lo, float hi) {       // saturate, then one v_cvt_pk_f16_f32 (RNE)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+    }
+    static __device__ inline unsigned pack2_nosat(float lo, float hi) {  // for values known to be in range (residues)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
     }
     static __device__ inline float lo(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu)); }
     static __device__ inline float hi(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16)); }
@@ -115,7 +125,56 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     // (the pipeline stages are free now) so that 8 (or 4) neighbouring lanes cover the contiguous channels
     // of one pixel: residual planes are read and output planes written as full 16-byte-per-lane rows.
     constexpr int EP = WTN + 4;                       // floats per tile row (+4: conflict-free ds_write_b128)
+    constexpr int LPR = WTN / 8;                      // lanes per pixel row (8 channels each)
+    constexpr int RPP = 64 / LPR;                     // pixel rows per pass
+    constexpr int NPASS = WTM / RPP;
+    // BN scale / shift of this lane's channels: ALL loads issued back to back, branch-free (clamped indices,
+    // out-of-range lanes load valid garbage they never store) -- one L2 round trip instead of one per group.
+    const bool has_alpha = p.alpha != nullptr;
+    const float* asrc = has_alpha ? p.alpha : p.beta;
+    f32x4 alv[NT][4], bev[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * lhi;
+            if constexpr (OUT_F32) {          // head conv: cout (255) is not a multiple of 4 -> element-wise
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nn = n + q < p.Cout ? n + q : p.Cout - 1;
+                    bev[i][g][q] = p.beta[nn]; alv[i][g][q] = asrc[nn];
+                }
+            } else {
+                const int nn = n < p.Cout ? n : 0;
+                bev[i][g] = *reinterpret_cast<const f32x4*>(p.beta + nn);
+                alv[i][g] = *reinterpret_cast<const f32x4*>(asrc + nn);
+            }
+        }
+    // Residual rows are fetched next, all passes at once, so that their HBM latency is paid once and overlaps
+    // the BN/activation + LDS transpose below (fetching them pass by pass serialises NPASS round trips).
+    // NP = 3 would need 96 more registers than the 512-thread kernels have: it keeps the per-pass loads.
+    constexpr bool PRE = !OUT_F32 && NP <= 2;
+    u32x4 rres[PRE ? NPASS : 1][NP];
+    if constexpr (PRE) {
+        if (p.res) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int m = m0 + wm * WTM + ps * RPP + lane / LPR;
+                const int n = n0 + wn * WTN + (lane % LPR) * 8;
+                const long long o = (m < p.M && n < p.Cout) ? (long long)m * p.Cout + n : 0;      // clamped, unused if out of range
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) rres[ps][pl] = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
+            }
+        }
+    }
     // (launch_cfg sizes the dynamic LDS as max(pipeline, NW * WTM * EP * 4))
+    if (!has_alpha) {                                 // wave-uniform: plain bias convs
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) alv[i][g] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    const float slope = p.act == YV3_ACT_LEAKY ? 0.1f : 1.f;     // LeakyReLU(0.1) == max(t, 0.1 t); linear == max(t, t)
     if constexpr (SYNC) __syncthreads();              // every wave is done with the last stage
     float* tile = reinterpret_cast<float*>(lds) + wid * (WTM * EP);
 #pragma unroll
@@ -125,33 +184,20 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = i * 32 + 8 * g + 4 * lhi;                 // channel inside the wave tile
-                const int n = n0 + wn * WTN + nl;
-                f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-                if (OUT_F32) {          // head conv: cout (255) is not a multiple of 4 -> element-wise
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < p.Cout) { be[q] = p.beta[n + q]; if (p.alpha) al[q] = p.alpha[n + q]; }
-                } else if (n < p.Cout) {
-                    be = *reinterpret_cast<const f32x4*>(p.beta + n);
-                    if (p.alpha) al = *reinterpret_cast<const f32x4*>(p.alpha + n);
-                }
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float t = fmaf(acc[i][j][4 * g + q], al[q], be[q]);
-                    if (p.act == YV3_ACT_LEAKY) t = t > 0.f ? t : 0.1f * t;
-                    v[q] = t;
+                    const float t = fmaf(acc[i][j][4 * g + q], alv[i][g][q], bev[i][g][q]);
+                    v[q] = __builtin_fmaxf(t, slope * t);
                 }
                 *reinterpret_cast<f32x4*>(tile + (j * 32 + l31) * EP + nl) = v;
             }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bool ovf = false;
-    constexpr int LPR = WTN / 8;                      // lanes per pixel row (8 channels each)
-    constexpr int RPP = 64 / LPR;                     // pixel rows per pass
+    float amax = 0.f;                                 // running max |v| of what this lane stores (fp16 range check)
 #pragma unroll
-    for (int ps = 0; ps < WTM / RPP; ++ps) {
+    for (int ps = 0; ps < NPASS; ++ps) {
         const int r = ps * RPP + lane / LPR;
         const int cg = (lane % LPR) * 8;
         const int m = m0 + wm * WTM + r;
@@ -170,7 +216,9 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
             if (p.res) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {       // planes sum back to the exact fp32 value
-                    const u32x4 q4 = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
+                    u32x4 q4;
+                    if constexpr (PRE) q4 = rres[ps][pl];
+                    else q4 = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
 #pragma unroll
                     for (int h = 0; h < 4; ++h) { v[2 * h] += PlaneOps<NP>::lo(q4[h]); v[2 * h + 1] += PlaneOps<NP>::hi(q4[h]); }
                 }
@@ -178,22 +226,33 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
             u16* yo = (u16*)p.y + o;
             if constexpr (NP == 2) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ovf |= !(__builtin_fabsf(v[q]) <= 65504.f);
-            }
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                u32x4 q4;
+                for (int h = 0; h < 4; ++h) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
+                u32x4 qh, ql;
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    q4[h] = PlaneOps<NP>::pack2(v[2 * h], v[2 * h + 1]);
-                    v[2 * h] -= PlaneOps<NP>::lo(q4[h]); v[2 * h + 1] -= PlaneOps<NP>::hi(q4[h]);
+                    v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);           // saturate (and flag, below)
+                    v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
+                    qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
+                    ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
                 }
-                *reinterpret_cast<u32x4*>(yo + pl * p.ys) = q4;
+                *reinterpret_cast<u32x4*>(yo) = qh;
+                *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    u32x4 q4;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        q4[h] = PlaneOps<NP>::pack2(v[2 * h], v[2 * h + 1]);
+                        v[2 * h] -= PlaneOps<NP>::lo(q4[h]); v[2 * h + 1] -= PlaneOps<NP>::hi(q4[h]);
+                    }
+                    *reinterpret_cast<u32x4*>(yo + pl * p.ys) = q4;
+                }
             }
         }
     }
     if constexpr (NP == 2) {
-        if (p.flags && __any(ovf) && lane == 0) atomicOr(p.flags, 1);
+        if (p.flags && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.flags, 1);
     }
 }
 
