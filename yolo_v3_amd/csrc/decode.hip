@@ -23,33 +23,45 @@ struct DecodeArgs {
 
 __device__ inline float sigmoidf_(float t) { return 1.f / (1.f + expf(-t)); }
 
+// One workgroup iteration = PPB consecutive pixels; thread -> channel ca of the 3*(5+C) per pixel (no
+// per-element integer division: anchor / attribute come from two compares, grid x/y once per pixel).
+constexpr int PPB = 4;
+
 template <bool NCHW>
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     const int b = blockIdx.y;
     const int HW = a.H * a.W;
     const int ch = 3 * a.attrib;
-    const long long per_batch = (long long)HW * ch;
-    const float* src = a.logits + (NCHW ? (long long)b * per_batch : (long long)b * HW * a.ld);
+    const float* src = a.logits + (NCHW ? (long long)b * HW * ch : (long long)b * HW * a.ld);
     float* dst = a.out + (long long)b * a.out_batch_stride;
-    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < per_batch; r += (long long)gridDim.x * 256) {
-        const int pix = (int)(r / ch);
-        const int ca = (int)(r - (long long)pix * ch);
-        const int anc = ca / a.attrib;
+    for (int ca = threadIdx.x; ca < ch; ca += 256) {
+        const int anc = (ca >= a.attrib) + (ca >= 2 * a.attrib);
         const int attr = ca - anc * a.attrib;
-        const float t = NCHW ? src[(long long)ca * HW + pix] : src[(long long)pix * a.ld + ca];
-        float v;
-        if (attr >= 4) {
-            v = sigmoidf_(t);
-        } else if (attr == 0) {
-            v = (sigmoidf_(t) + (float)(pix % a.W)) * a.stride;
-        } else if (attr == 1) {
-            v = (sigmoidf_(t) + (float)(pix / a.W)) * a.stride;
-        } else if (attr == 2) {
-            v = (expf(t) * a.aw[anc]) * a.stride;
-        } else {
-            v = (expf(t) * a.ah[anc]) * a.stride;
+        const float an = attr == 2 ? a.aw[anc] : a.ah[anc];
+        for (int p0 = blockIdx.x * PPB; p0 < HW; p0 += gridDim.x * PPB) {
+            float t[PPB];
+#pragma unroll
+            for (int k = 0; k < PPB; ++k) {
+                const int pix = p0 + k < HW ? p0 + k : HW - 1;
+                t[k] = NCHW ? src[(long long)ca * HW + pix] : src[(long long)pix * a.ld + ca];
+            }
+#pragma unroll
+            for (int k = 0; k < PPB; ++k) {
+                const int pix = p0 + k;
+                if (pix >= HW) break;
+                float v;
+                if (attr >= 4) {
+                    v = sigmoidf_(t[k]);
+                } else if (attr == 0) {
+                    v = (sigmoidf_(t[k]) + (float)(pix % a.W)) * a.stride;
+                } else if (attr == 1) {
+                    v = (sigmoidf_(t[k]) + (float)(pix / a.W)) * a.stride;
+                } else {
+                    v = (expf(t[k]) * an) * a.stride;
+                }
+                dst[(long long)pix * ch + ca] = v;
+            }
         }
-        dst[r] = v;
     }
 }
 
@@ -61,9 +73,8 @@ int run(const float* logits, int ld, const float* anchors, float stride, float* 
     a.H = H; a.W = W; a.attrib = 5 + C; a.stride = stride;
     if (!nchw && ld < 3 * a.attrib) return YV3_ESHAPE;
     for (int i = 0; i < 3; ++i) { a.aw[i] = anchors[2 * i] / stride; a.ah[i] = anchors[2 * i + 1] / stride; }
-    const long long per_batch = (long long)H * W * 3 * a.attrib;
-    const int bx = (int)((per_batch + 255) / 256 < 2048 ? (per_batch + 255) / 256 : 2048);
-    const dim3 grid((unsigned)bx, (unsigned)B);
+    const int groups = (H * W + PPB - 1) / PPB;
+    const dim3 grid((unsigned)(groups < 1024 ? groups : 1024), (unsigned)B);
     if (nchw) hipLaunchKernelGGL(decode_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else      hipLaunchKernelGGL(decode_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     YV3_CHECK_LAUNCH();
