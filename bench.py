@@ -210,8 +210,10 @@ def main():
         # HBM traffic of the dominant kernel family comes from separate rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE cannot be sampled from inside this process); the committed summary for this exact
         # workload is attached when present (tools/traffic_summary.py, profiles/*_traffic_*.json).
-        tpath = os.path.join(REPO, "profiles", "r01b_traffic_%s_%d_bs%d.json" % (args.dtype, args.size, B))
-        if os.path.exists(tpath):
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic_%s_%d_bs%d.json" % (args.dtype, args.size, B))))
+        tpath = cands[-1] if cands else ""
+        if tpath:
             fam = json.load(open(tpath)).get(KERNEL_NAME[args.dtype].split("<")[0])
             if fam:
                 out["roofline"]["traffic"] = round(fam["hbm_bytes_per_step_fetch_x2"] / n_desc)
