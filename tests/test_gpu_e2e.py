@@ -1,5 +1,6 @@
 """End-to-end GPU parity: YoloNet.forward / detect() against the reference's golden outputs
 (tests/golden/e2e.npz, produced by the reference itself with SW-1 weights) and the CPU oracle."""
+import json
 import os
 
 import numpy as np
@@ -260,3 +261,61 @@ def test_fp16_plane_overflow_is_reported(sw1_stream):
     net.math_mode = _ffi.F32X3                                   # bf16 planes have fp32's exponent range: no error
     out = net.forward_cat(x)
     assert out.shape == (1, 10647, 85) and torch.isfinite(out[..., 4:]).all()
+
+
+# ----------------------------------------------------------------------------- COCO results writer
+def _coco_inputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "coco_results_inputs.npz"))
+    org, counts, flat, paths = g["org"], g["counts"], g["preds"], [str(p) for p in g["paths"]]
+    preds, k = [], 0
+    for n in counts:
+        preds.append(torch.from_numpy(flat[k:k + n].copy()) if n else torch.Tensor())
+        k += n
+    sample = {"img": torch.zeros(len(org), 3, 416, 416), "org_img": [torch.zeros(3, int(h), int(w)) for (w, h) in org],
+              "img_path": paths}
+    return sample, preds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lb", [0, 1])
+def test_coco_results_writer_matches_reference_bytes(golden_dir, tmp_path, lb):
+    """yolo_v3_amd.evaluate.JsonPredictionWriter (boxes through yv3_correct_boxes) writes the byte-identical file
+    the reference's evaluate.JsonPredictionWriter wrote for the same predictions (oracle/make_golden_coco.py)."""
+    from yolo_v3_amd import evaluate
+    sample, preds = _coco_inputs(golden_dir)
+    out = str(tmp_path / "res.json")
+    with evaluate.open_json_pred_writer(out, None, bool(lb)) as wr:
+        wr.process_batch(sample, preds)
+    want = open(os.path.join(golden_dir, "coco_results_lb%d.json" % lb)).read()
+    assert open(out).read() == want
+    assert len(json.loads(want)) == 13
+
+
+@pytest.mark.gpu
+def test_predict_and_process_eval_mode(tmp_path, net):
+    """reference evaluate.py:197-206 end to end on synthetic scenes: eval-mode detections handed to a BatchHandler
+    equal detect()'s at the same thresholds (conf 0.4 here: with synthetic weights the reference's 0.005 floor
+    passes > 5e5 (row, class) pairs per image), and the JSON written from them parses, one entry per box."""
+    from yolo_v3_amd import evaluate
+    net.img_dim = (416, 416)
+    x = torch.from_numpy(synth.images(2, 416, 77))
+    sample = {"img": x, "org_img": [torch.zeros(3, 480, 640), torch.zeros(3, 333, 500)],
+              "img_path": ["a/COCO_val2014_000000000042.jpg", "b/000000000007.jpg"]}
+
+    class Rec(evaluate.BatchHandler):
+        def process_batch(self, sample, predictions):
+            self.n = [int(p.shape[0]) if p.numel() else 0 for p in predictions]
+            self.pred = predictions
+    rec = Rec()
+    evaluate.predict_and_process([sample], net, 80, rec, obj_conf_thr=0.4)
+    want = detect(net, x.cuda(), 80, 0.4, 0.45, True, True)
+    assert rec.n == [int(p.shape[0]) for p in want] and sum(rec.n) > 0
+    out = str(tmp_path / "r.json")
+    with evaluate.open_json_pred_writer(out, None, True) as wr:
+        wr.process_batch(sample, [p[:50] for p in rec.pred])
+    js = json.load(open(out))
+    assert len(js) == sum(min(n, 50) for n in rec.n)
+    assert {e["image_id"] for e in js} <= {42, 7} and all(len(e["bbox"]) == 4 for e in js)
+    for e in js:
+        w, h = (640, 480) if e["image_id"] == 42 else (500, 333)
+        assert 0 <= e["bbox"][0] <= w and 0 <= e["bbox"][1] <= h and e["bbox"][0] + e["bbox"][2] <= w + 1e-3

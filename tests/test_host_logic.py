@@ -151,3 +151,18 @@ def test_synth_is_reproducible():
     assert img.shape == (2, 3, 64, 64) and img.dtype == np.float32 and 0 <= img.min() and img.max() <= 1
     assert sha(img) == sha(synth.images(2, 64, 5))
     assert not np.array_equal(img[0], img[1])
+
+
+def test_coco_writer_host_logic(tmp_path):
+    """image ids, entry layout and the empty-run case of yolo_v3_amd.evaluate (no GPU work: no detections)."""
+    import json
+    from yolo_v3_amd import evaluate
+    assert evaluate.get_image_id_from_path("/d/COCO_val2014_000000000139.jpg") == 139
+    assert evaluate.get_image_id_from_path("frame_42.jpeg") == 42
+    e = evaluate.create_results_entry(1, 2, [0.0, 1.0, 2.0, 3.0], 0.5)
+    assert list(e.keys()) == ["image_id", "category_id", "bbox", "score"]
+    out = str(tmp_path / "empty.json")
+    import torch
+    with evaluate.open_json_pred_writer(out, None, True) as wr:
+        wr.process_batch({"img": torch.zeros(1, 3, 32, 32), "org_img": [torch.zeros(3, 8, 8)], "img_path": ["x_1.jpg"]}, [torch.Tensor()])
+    assert json.load(open(out)) == []
