@@ -129,7 +129,7 @@ def main():
             s = _ffi.stream_ptr()
             p0 = eng.packed[0]
             _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
-                                     plan.conv0_out.data_ptr(), B, plan.H, plan.W, codes[mode], s))
+                                     plan.conv0_out.data_ptr(), B, plan.H, plan.W, codes[mode], plan.flags.data_ptr(), s))
             if timed:
                 e0.record()
             _ffi.check(lib.yv3_conv2d_sequence(plan.descs, plan.n_desc, s))

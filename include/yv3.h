@@ -82,11 +82,14 @@ int yv3_merge_planes(const void* in, float* out, long long n, int np, void* stre
 
 /* First layer, feature.mlist.0: 3 -> 32 channels, 3x3, stride 1, pad 1, + BN + leaky.
  * x is the caller's NCHW fp32 image batch [B,3,H,W] (values in [0,1]); y is NHWC [B,H,W,32] in
- * out_dtype (fp32, or 1 / 3 bf16 planes).
+ * out_dtype (fp32, 1 / 3 bf16 planes, or 2 fp16 planes).
  * w_tap_major is the OIHW weight permuted to [cin][kh][kw][cout] = [27][32] fp32;
- * alpha/beta from yv3_fold_bn. */
+ * alpha/beta from yv3_fold_bn.
+ * flags (device pointer, may be NULL): YV3_F32_F16X2 runs this layer on the fp16 matrix cores with
+ * inputs scaled by 2^4 and weights by 2^8; |x| > 4094 or |w| > 255 cannot be represented and OR bit 0
+ * into *flags (the same sticky status word as yv3_conv_desc.flags). */
 int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
-              void* y_nhwc, int B, int H, int W, int out_dtype, void* stream);
+              void* y_nhwc, int B, int H, int W, int out_dtype, int* flags, void* stream);
 
 typedef struct yv3_conv_desc {
     const void*  x;         /* NHWC [B,H,W,cin] -- or, when cin_up > 0, the LOW-resolution map

@@ -242,6 +242,33 @@ def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W, mode):
     assert_close_rel(out, ref, 2e-5, "split conv mode %d %s" % (mode, (cin, cout, k, s)))
 
 
+@pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3, _ffi.F32H2])
+@pytest.mark.parametrize("B,H,W", [(2, 40, 56), (1, 9, 131), (3, 64, 32), (1, 33, 260)])
+def test_first_layer_all_modes_vs_fp64(B, H, W, mode):
+    """yv3_conv0 (darknet.py:76): direct VALU kernel (fp32 / bf16x3 outputs) and the matrix-core kernel of the
+    fp16-plane mode (K = 27 padded to 32, permuted channel rows, LDS-staged patch) on shapes with row / column
+    tails and partial 128-column workgroup tiles; fp32-class tolerance 2e-5 * max(1,|ref|), and the un-split planes
+    reproduce the value exactly as stored."""
+    m = _rand_cbr(3, 32, 3, 1, seed=5)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3))
+    ref = _ref_cbr(m, x)
+    mc = m.cuda()
+    pc = engine.pack_conv(mc, mc._spec(), mode)
+    y = engine.alloc_act(B, H, W, 32, mode, "cuda")
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    xg = x.cuda().contiguous()
+    _ffi.check(_ffi.lib().yv3_conv0(xg.data_ptr(), pc.w.data_ptr(), pc.alpha.data_ptr(), pc.beta.data_ptr(), y.data_ptr(),
+                                    B, H, W, mode, flags.data_ptr(), _ffi.stream_ptr()))
+    out = engine.from_planes(y, mode).permute(0, 3, 1, 2).cpu()
+    assert_close_rel(out, ref, 2e-5, "first layer mode %d" % mode)
+    assert int(flags.item()) == 0
+    if mode == _ffi.F32H2:                      # inputs beyond the scaled fp16 range are reported, not silently wrong
+        xg[0, 1, 3, 4] = 5000.0
+        _ffi.check(_ffi.lib().yv3_conv0(xg.data_ptr(), pc.w.data_ptr(), pc.alpha.data_ptr(), pc.beta.data_ptr(), y.data_ptr(),
+                                        B, H, W, mode, flags.data_ptr(), _ffi.stream_ptr()))
+        assert int(flags.item()) == 1
+
+
 @pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(32, 64, 3, 2, 2, 40, 56), (128, 256, 3, 1, 5, 13, 13), (512, 256, 1, 1, 33, 13, 13),
                                                  (256, 128, 1, 1, 64, 26, 26), (512, 1024, 3, 1, 24, 13, 13)])
 def test_conv_bf16_mode_vs_fp64(cin, cout, k, s, B, H, W):

@@ -17,7 +17,7 @@ ref = None
 for name, dt in (("f32", _ffi.F32), ("f32h2", _ffi.F32H2), ("f32x3", _ffi.F32X3), ("bf16", _ffi.BF16)):
     pc = engine.pack_conv(m, m._spec(), dt)
     y = engine.alloc_act(B, S, S, 32, dt, "cuda")
-    call = lambda: _ffi.check(lib.yv3_conv0(x.data_ptr(), pc.w.data_ptr(), pc.alpha.data_ptr(), pc.beta.data_ptr(), y.data_ptr(), B, S, S, dt, st))
+    call = lambda: _ffi.check(lib.yv3_conv0(x.data_ptr(), pc.w.data_ptr(), pc.alpha.data_ptr(), pc.beta.data_ptr(), y.data_ptr(), B, S, S, dt, None, st))
     for _ in range(3): call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

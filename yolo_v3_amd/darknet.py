@@ -88,7 +88,7 @@ def _first_conv(module, x_nchw):
         pc = _engine.pack_conv(module, sp, _ffi.F32)
         y = torch.empty((B, H, W, 32), device=x.device, dtype=torch.float32)
         _ffi.check(lib.yv3_conv0(x.data_ptr(), pc.w.data_ptr(), pc.alpha.data_ptr(), pc.beta.data_ptr(),
-                                 y.data_ptr(), B, H, W, _ffi.F32, _ffi.stream_ptr()), "yv3_conv0")
+                                 y.data_ptr(), B, H, W, _ffi.F32, None, _ffi.stream_ptr()), "yv3_conv0")
     return y
 
 

@@ -278,7 +278,7 @@ class Engine:
         s = _ffi.stream_ptr()
         p0 = self.packed[0]
         _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
-                                 plan.conv0_out.data_ptr(), plan.B, plan.H, plan.W, self.dtype, s), "yv3_conv0")
+                                 plan.conv0_out.data_ptr(), plan.B, plan.H, plan.W, self.dtype, plan.flags.data_ptr(), s), "yv3_conv0")
         _ffi.check(lib.yv3_conv2d_sequence(plan.descs, plan.n_desc, s), "yv3_conv2d_sequence")
 
     def run_decode(self, plan, dets):
