@@ -106,28 +106,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     // ---- DMA of one K chunk = G wave instructions ("pieces").  dma_prepare computes this lane's source
     // pointers once per chunk; dma_piece(idx) issues one global_load_lds, so that the pieces can be spread
     // between the MFMAs of the previous chunk instead of being issued as one burst behind the barrier.
+    // The per-lane source pointer only changes shape when the filter tap changes (every Cin/32 chunks): bounds
+    // test, base pointer and plane stride are recomputed there; inside a tap a chunk is one 64-bit add.
     const u16* ap[AQ];
     long long aps[AQ];
+    int ainc[AQ];
     const u16* wbp = p.w;
     unsigned char* dst = lds;
     auto dma_prepare = [&](int kc, int stage) {
         dst = lds + stage * STAGE;
+        if (DUAL) {
 #pragma unroll
-        for (int q = 0; q < AQ; ++q) {
-            bool ok = aok[q];
-            const u16* src = p.x;
-            long long off, ps = p.xs;
-            if (K3) {
-                ok = ok && (unsigned)(ahi[q] + kh) < (unsigned)p.H && (unsigned)(awi[q] + kw) < (unsigned)p.W;
-                off = aoff[q] + ((long long)kh * p.W + kw) * p.Cin + c0;
-            } else if (DUAL) {
+            for (int q = 0; q < AQ; ++q) {
+                const bool ok = aok[q];
+                const u16* src = p.x;
+                long long off, ps = p.xs;
                 if (c0 < p.Cup) off = aoff[q] + c0;
                 else { src = p.x2; off = aoff2[q] + (c0 - p.Cup); ps = p.x2s; }
-            } else {
-                off = aoff[q] + c0;
+                ap[q] = ok ? src + off : g_zero_page;
+                aps[q] = ok ? ps : 0;
             }
-            ap[q] = ok ? src + off : g_zero_page;
-            aps[q] = ok ? ps : 0;
+        } else if (c0 == 0) {                                  // wave-uniform: first chunk of a tap (or of a 1x1 conv)
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) {
+                bool ok = aok[q];
+                long long off = aoff[q];
+                if (K3) {
+                    ok = ok && (unsigned)(ahi[q] + kh) < (unsigned)p.H && (unsigned)(awi[q] + kw) < (unsigned)p.W;
+                    off += ((long long)kh * p.W + kw) * p.Cin;
+                }
+                ap[q] = ok ? p.x + off : g_zero_page;
+                aps[q] = ok ? p.xs : 0;
+                ainc[q] = ok ? PBK : 0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) ap[q] += ainc[q];
         }
         wbp = p.w + ((btile + kc) * NP) * (long long)(p.tb * PBK) + bin;
         c0 += PBK;
