@@ -111,8 +111,22 @@ typedef struct yv3_conv_desc {
     int out_dtype;          /* format of y: == dtype, or YV3_F32 (head convs write fp32 logits) */
     int* flags;             /* optional device int32: bit 0 is OR-ed in when a YV3_F32_F16X2 output had to be
                                saturated (|value| > 65504), i.e. the fp16 planes cannot represent this
-                               layer -- rerun in YV3_F32_BF16X3 or YV3_F32.  NULL: not reported.           */
+                               layer -- rerun in YV3_F32_BF16X3 or YV3_F32.  NULL: not reported.
+                               Bit 1: internal scheduling error (stream-K hand-over timed out).           */
+    void*  workspace;       /* optional device scratch of yv3_conv_workspace_bytes() bytes, ZERO-FILLED once by
+                               the caller and then left alone: enables the persistent "stream-K" schedule of the
+                               YV3_F32_F16X2 kernels (every CU gets the same number of K chunks; a tile split
+                               between two workgroups is finished by the first with the accumulators the second
+                               left here), used for launches of fewer than two rounds of tiles.  One workspace
+                               per stream: launches that may overlap must not share it.  Opt-in because a
+                               split tile is summed head + tail: results stay within the parity tolerance but
+                               are no longer bit-identical for the same image at different batch positions.
+                               NULL: one tile per workgroup (bitwise batch-independent).                    */
+    size_t workspace_bytes;
 } yv3_conv_desc;
+
+/* Size of yv3_conv_desc.workspace. */
+size_t yv3_conv_workspace_bytes(void);
 
 /* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */
 int yv3_conv2d(const yv3_conv_desc* desc, void* stream);

@@ -319,3 +319,19 @@ def test_predict_and_process_eval_mode(tmp_path, net):
     for e in js:
         w, h = (640, 480) if e["image_id"] == 42 else (500, 333)
         assert 0 <= e["bbox"][0] <= w and 0 <= e["bbox"][1] <= h and e["bbox"][0] + e["bbox"][2] <= w + 1e-3
+
+
+@pytest.mark.gpu
+def test_stream_k_schedule_end_to_end(golden_dir, sw1_stream):
+    """net.stream_k = True (opt-in persistent schedule of the 13x13 layers): detections at bs=64 stay within the
+    parity tolerance of the default schedule's (which is golden-checked above) -- bitwise equality is NOT expected,
+    a split tile is summed head + tail -- and the kept boxes agree."""
+    x = torch.from_numpy(synth.images(64, 416, 4242)).cuda()
+    a = load_sw1_net(sw1_stream).cuda()
+    b = load_sw1_net(sw1_stream).cuda()
+    b.stream_k = True
+    da, db = a.forward_cat(x).cpu(), b.forward_cat(x).cpu()
+    assert b.engine().plan(64, 416, 416).workspace is not None and a.engine().plan(64, 416, 416).workspace is None
+    assert_close_rel(db, da.double(), TOL, "stream-K vs default schedule")      # two fp32-round-off paths, 75 layers deep
+    ra, rb = detect(a, x), detect(b, x)
+    assert [int(r.shape[0]) for r in ra] == [int(r.shape[0]) for r in rb]

@@ -242,6 +242,38 @@ def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W, mode):
     assert_close_rel(out, ref, 2e-5, "split conv mode %d %s" % (mode, (cin, cout, k, s)))
 
 
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(512, 1024, 3, 1, 64, 13, 13), (1024, 512, 1, 1, 64, 13, 13), (256, 512, 3, 2, 50, 26, 26),
+                                                (512, 1024, 3, 1, 47, 13, 13)])
+def test_conv_stream_k_schedule(cin, cout, k, s, B, H, W):
+    """Opt-in stream-K schedule (yv3_conv_desc.workspace) on launches of 1-2 rounds of tiles: every CU owns an equal
+    range of (tile, K-chunk) iterations; split tiles are finished by the workgroup holding the head part with the
+    accumulators its XCD neighbour left in the workspace.  Same fp32-class tolerance vs fp64 as the plain schedule,
+    the hand-over flags are all cleared again, no scheduling error is flagged, and a second launch reproduces the
+    first bit for bit (the split points are a function of the shape only)."""
+    mode = _ffi.F32H2
+    m = _rand_cbr(cin, cout, k, s, seed=cin + cout + k)
+    x = torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(1)) * 2 - 0.5
+    ho, wo = engine.out_hw(H, W, k, s)
+    res = torch.rand(B, cout, ho, wo, generator=torch.Generator().manual_seed(2)) - 0.5
+    ref = _ref_cbr(m, x) + res.double()
+    mc = m.cuda()
+    pc = engine.pack_conv(mc, mc._spec(), mode)
+    xp = engine.to_planes(x.cuda().permute(0, 2, 3, 1).contiguous(), mode)
+    rp = engine.to_planes(res.cuda().permute(0, 2, 3, 1).contiguous(), mode)
+    y = engine.alloc_act(B, ho, wo, cout, mode, "cuda")
+    ws = torch.zeros(_ffi.lib().yv3_conv_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d = engine.make_desc(pc, xp, y, B, H, W, rp, dtype=mode, flags=flags, workspace=ws)
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    out = engine.from_planes(y, mode).permute(0, 3, 1, 2).cpu()
+    assert_close_rel(out, ref, 2e-5, "stream-K conv %s" % ((cin, cout, k, s, B),))
+    assert int(flags.item()) == 0
+    assert int(ws[-4 * 512:].view(torch.int32).abs().sum()) == 0          # every hand-over flag consumed
+    first = y.clone()
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    assert torch.equal(y, first)
+
+
 @pytest.mark.parametrize("mode", [_ffi.F32, _ffi.F32X3, _ffi.F32H2])
 @pytest.mark.parametrize("B,H,W", [(2, 40, 56), (1, 9, 131), (3, 64, 32), (1, 33, 260)])
 def test_first_layer_all_modes_vs_fp64(B, H, W, mode):

@@ -24,11 +24,13 @@ class ConvDesc(ctypes.Structure):
                 ("residual", c_void_p), ("y", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("cin", c_int), ("cin_up", c_int),
                 ("cout", c_int), ("cout_pad", c_int), ("k", c_int), ("stride", c_int), ("act", c_int),
-                ("dtype", c_int), ("out_dtype", c_int), ("flags", c_void_p)]
+                ("dtype", c_int), ("out_dtype", c_int), ("flags", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
 _SIGNATURES = {
     "yv3_version": (c_int, []),
+    "yv3_conv_workspace_bytes": (ctypes.c_size_t, []),
     "yv3_error_string": (ctypes.c_char_p, [c_int]),
     "yv3_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_fold_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),

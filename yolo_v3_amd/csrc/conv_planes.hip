@@ -25,9 +25,6 @@
 
 namespace {
 
-#ifndef YV3_PP_DMA
-#define YV3_PP_DMA 1
-#endif
 #ifndef YV3_PP_GRP
 #define YV3_PP_GRP(wid) ((wid) >> 2)
 #endif
@@ -37,7 +34,7 @@ namespace {
 // fragments of the next chunk from LDS and issues its share of the DMA, then they swap at an s_barrier.
 // Each SIMD's matrix pipe is thereby fed by one wave while its partner wave loads, instead of both
 // waves stalling on LDS / DMA / barrier at the same time.
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false>
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvParamsP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile: WTM pixels x WTN channels
@@ -57,13 +54,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     const unsigned long long tl_entry = __builtin_amdgcn_s_memtime();
 #endif
 
-    if (PP && p.stagger && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    const int bid = yv3_xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (bid % p.ntiles) * BN;
-    const int m0 = (bid / p.ntiles) * BM;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,32 +66,44 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     int ahi[K3 ? AQ : 1], awi[K3 ? AQ : 1];
     bool aok[AQ];
     const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int q = 0; q < AQ; ++q) {
-        const int m = m0 + AROWS * wid + q * RPG + (lane >> 2);
-        aok[q] = m < p.M;
-        const int mm = aok[q] ? m : 0;
-        const int b = mm / HoWo;
-        const int rem = mm - b * HoWo;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
-        if (K3) {
-            ahi[q] = ho * p.stride - 1; awi[q] = wo * p.stride - 1;
-            aoff[q] = (((long long)b * p.H + ahi[q]) * p.W + awi[q]) * p.Cin + sslot;
-        } else if (DUAL) {
-            aoff[q] = (((long long)b * (p.H >> 1) + (ho >> 1)) * (p.W >> 1) + (wo >> 1)) * p.Cup + sslot;
-            aoff2[q] = (((long long)b * p.H + ho) * p.W + wo) * (p.Cin - p.Cup) + sslot;
-        } else {
-            aoff[q] = (((long long)b * p.H + ho * p.stride) * p.W + wo * p.stride) * p.Cin + sslot;
-        }
-    }
     // ---- staging, weight side: the packed tile is already in LDS-image (swizzled) order
     const bool bact = lane < BROWS * SLOTS;
-    const int brow = n0 % p.tb + BROWS * wid + (lane >> 2);
-    const long long btile = (long long)(n0 / p.tb) * p.nk;
-    const int bin = brow * PBK + (lane & (SLOTS - 1)) * 8;
-
+    int m0 = 0, n0 = 0, bin = 0;
+    long long btile = 0;
     int kh = 0, kw = 0, c0 = 0;
+    bool tapinit = true;
+    // index math of one workgroup tile (logical id `bid`), positioned at K chunk k0
+    auto setup_tile = [&](int bid, int k0) {
+        n0 = (bid % p.ntiles) * BN;
+        m0 = (bid / p.ntiles) * BM;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int m = m0 + AROWS * wid + q * RPG + (lane >> 2);
+            aok[q] = m < p.M;
+            const int mm = aok[q] ? m : 0;
+            const int b = mm / HoWo;
+            const int rem = mm - b * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            if (K3) {
+                ahi[q] = ho * p.stride - 1; awi[q] = wo * p.stride - 1;
+                aoff[q] = (((long long)b * p.H + ahi[q]) * p.W + awi[q]) * p.Cin + sslot;
+            } else if (DUAL) {
+                aoff[q] = (((long long)b * (p.H >> 1) + (ho >> 1)) * (p.W >> 1) + (wo >> 1)) * p.Cup + sslot;
+                aoff2[q] = (((long long)b * p.H + ho) * p.W + wo) * (p.Cin - p.Cup) + sslot;
+            } else {
+                aoff[q] = (((long long)b * p.H + ho * p.stride) * p.W + wo * p.stride) * p.Cin + sslot;
+            }
+        }
+        const int brow = n0 % p.tb + BROWS * wid + (lane >> 2);
+        btile = (long long)(n0 / p.tb) * p.nk;
+        bin = brow * PBK + (lane & (SLOTS - 1)) * 8;
+        const int cpt = p.Cin / PBK;                           // chunks per filter tap
+        const int tap = K3 ? k0 / cpt : 0;
+        kh = tap / 3; kw = tap - kh * 3; c0 = (k0 - tap * cpt) * PBK;
+        tapinit = true;
+    };
+    if (!(PP && SK)) setup_tile(yv3_xcd_remap(blockIdx.x, gridDim.x), 0);
 
     // ---- DMA of one K chunk = G wave instructions ("pieces").  dma_prepare computes this lane's source
     // pointers once per chunk; dma_piece(idx) issues one global_load_lds, so that the pieces can be spread
@@ -126,11 +128,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                 ap[q] = ok ? src + off : g_zero_page;
                 aps[q] = ok ? ps : 0;
             }
-        } else if (c0 == 0) {                                  // wave-uniform: first chunk of a tap (or of a 1x1 conv)
+        } else if (c0 == 0 || tapinit) {                       // wave-uniform: first chunk of a tap / of the tile
+            tapinit = false;
 #pragma unroll
             for (int q = 0; q < AQ; ++q) {
                 bool ok = aok[q];
-                long long off = aoff[q];
+                long long off = aoff[q] + c0;
                 if (K3) {
                     ok = ok && (unsigned)(ahi[q] + kh) < (unsigned)p.H && (unsigned)(awi[q] + kw) < (unsigned)p.W;
                     off += ((long long)kh * p.W + kw) * p.Cin;
@@ -172,13 +175,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     const int w_row = NP * A_PLANE + (wn * WTN + l31) * ROWB;                   // weight fragments (A operand)
     const int fsw = swz(l31);
 
+    if constexpr (!PP) {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < p.nk) {
-            dma_prepare(d, d);
+        for (int d = 0; d < D; ++d)
+            if (d < p.nk) {
+                dma_prepare(d, d);
 #pragma unroll
-            for (int g = 0; g < G; ++g) dma_piece(g);
-        }
+                for (int g = 0; g < G; ++g) dma_piece(g);
+            }
+    }
 
     constexpr int KS = PBK / 16;              // MFMA k-steps per chunk
     constexpr int NF = (NT + MT) * NP;        // fragments (ds_read_b128) per k-step
@@ -198,116 +203,172 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
         // 32x64 wave tiles (128x128 workgroup tile): the compute segment is only 12 MFMAs per k-step, so the second
         // k-step's fragments are fetched under the first k-step's MFMAs; measured +5 % there, -5 % on 64x64 wave tiles
         constexpr bool SPLIT = MT == 1;
-        if (D <= p.nk) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();       // chunk 0 has landed
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();                           // group 1 runs one segment behind
 #ifdef YV3_TIMELINE
-        const unsigned long long tl_loop0 = __builtin_amdgcn_s_memtime();
-        unsigned long long tl_load = 0, tl_b1 = 0, tl_comp = 0, tl_b2 = 0, tl_t = tl_loop0;
-        unsigned long long tl_l1 = 0, tl_l2 = 0, tl_l3 = 0;
+        unsigned long long tl_load = 0, tl_b1 = 0, tl_comp = 0, tl_b2 = 0, tl_pro = 0, tl_epi = 0, tl_t = tl_entry;
+        int tl_items = 0, tl_chunks = 0;
 #define TL_MARK(acc_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - tl_t; tl_t = t_; } while (0)
 #else
 #define TL_MARK(acc_) do {} while (0)
 #endif
-        int cur = 0, nxt = D % NSTAGE;
-        for (int kc = 0; kc < p.nk; ++kc) {
-            // ---- load segment: fragments of chunk kc -> registers, DMA of chunk kc+D -> the stage chunk kc-1 used
-            st = lds + cur * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < (SPLIT ? 1 : KS); ++ks)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) read_frag(ks, f);
-            const bool more = kc + D < p.nk;
-#ifdef YV3_TIMELINE
-            __builtin_amdgcn_sched_barrier(0);
-            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_l1 += t_ - tl_t; }
-#endif
-#if YV3_PP_DMA == 0
-            if (more) {
-                dma_prepare(kc + D, nxt);
-#pragma unroll
-                for (int g = 0; g < G; ++g) dma_piece(g);
-                wait_vmcnt<(D - 1) * G>();                                    // my pieces of chunk kc+1 have landed
-            } else {
-                wait_vmcnt<0>();
+        // ---- work list.  One tile, all of K, per workgroup -- or (SK, "stream-K") a persistent workgroup per CU that
+        // owns a contiguous range [it, it_end) of (tile, K chunk) iterations of ITS XCD's tile range, so that every CU
+        // gets the same number of chunks whatever the tile count (no idle CUs in a last partial round).  A range starts
+        // with the TAIL part [k0, nk) of a tile (accumulators dumped to the workspace) and ends with the HEAD part
+        // [0, k1) of another, whose tail the next workgroup of the same XCD dumped at ITS start, long ago: head + tail
+        // are added in that fixed order and the epilogue runs once.  Ranges are >= nk chunks (host guarantees tiles >=
+        // workgroups), so a tile is never split three ways.
+        int it = 0, it_end = p.nk, tile_base = 0;
+        if constexpr (SK) {
+            const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nj = gridDim.x >> 3;
+            const int t0 = (int)((long long)xcd * p.total / 8), t1 = (int)((long long)(xcd + 1) * p.total / 8);
+            const long long tx = (long long)(t1 - t0) * p.nk;
+            it = (int)(tx * jb / nj); it_end = (int)(tx * (jb + 1) / nj); tile_base = t0;
+        }
+        bool first_item = true;
+        while (it < it_end) {
+            int k0 = 0, k1 = p.nk;
+            if constexpr (SK) {
+                const int tl = it / p.nk;
+                k0 = it - tl * p.nk;
+                k1 = it_end - it < p.nk - k0 ? k0 + (it_end - it) : p.nk;
+                setup_tile(tile_base + tl, k0);
+                if (!first_item) __syncthreads();                                 // the previous item's epilogue tiles are dead
             }
-#else
-            // addresses now (VALU, off the matrix pipe's critical path); the pieces go out between the MFMAs of
-            // the compute segment.  My pieces of chunk kc+1 (issued D-1 compute segments ago) must have landed.
-            if (more) dma_prepare(kc + D, nxt);
-#ifdef YV3_TIMELINE
-            __builtin_amdgcn_sched_barrier(0);
-            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_l2 += t_ - tl_t; }
-#endif
-            if (kc + D - 1 < p.nk) wait_vmcnt<(D - 2) * G>(); else wait_vmcnt<0>();
-#ifdef YV3_TIMELINE
-            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_l3 += t_ - tl_t; }
-#endif
-#endif
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            TL_MARK(tl_load);
-            __builtin_amdgcn_s_barrier();
-            TL_MARK(tl_b1);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- compute segment: registers only (SPLIT: plus the second k-step's fragment reads)
-            if constexpr (SPLIT) {
 #pragma unroll
-                for (int ks = 1; ks < KS; ++ks)
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (k0 + d < k1) {
+                    dma_prepare(k0 + d, d);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) dma_piece(g);
+                }
+            // chunk k0 has landed.  After an epilogue its stores sit behind these pieces in the (load/store-mixed) vmcnt
+            // queue, so later items drain it completely.
+            if (first_item && k0 + D <= k1) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1) __builtin_amdgcn_s_barrier();                           // group 1 runs one segment behind
+            TL_MARK(tl_pro);
+            int cur = 0, nxt = D % NSTAGE;
+            for (int kc = k0; kc < k1; ++kc) {
+                // ---- load segment: fragments of chunk kc -> registers; addresses of chunk kc+D (VALU, off the matrix
+                // pipe's critical path).  My pieces of chunk kc+1 (issued D-1 compute segments ago) must have landed.
+                st = lds + cur * STAGE;
+#pragma unroll
+                for (int ks = 0; ks < (SPLIT ? 1 : KS); ++ks)
 #pragma unroll
                     for (int f = 0; f < NF; ++f) read_frag(ks, f);
-            }
+                const bool more = kc + D < k1;
+                if (more) dma_prepare(kc + D, nxt);
+                if (kc + D - 1 < k1) wait_vmcnt<(D - 2) * G>(); else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                TL_MARK(tl_load);
+                __builtin_amdgcn_s_barrier();
+                TL_MARK(tl_b1);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- compute segment: MFMAs from registers, the DMA pieces of chunk kc+D between them
+                // (SPLIT: plus the second k-step's fragment reads)
+                if constexpr (SPLIT) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (SPLIT && ks == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-                if constexpr (NP == 2) {                                       // rotate over the accumulators: no back-to-back RAW
+                    for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                        for (int f = 0; f < NF; ++f) read_frag(ks, f);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (SPLIT && ks == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)                                    // rotate over the accumulators: no back-to-back RAW
 #pragma unroll
                         for (int u = 0; u < NU; ++u) {
                             const int i = u / MT, j = u % MT;
                             const bf16x8v* wf = &frag[ks][i * NP];
                             const bf16x8v* xf = &frag[ks][NT * NP + j * NP];
                             acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
-#if YV3_PP_DMA != 0
-                            {   // one DMA piece after every (24 / G)-th MFMA
-                                constexpr int TOT = KS * 3 * NU;
-                                const int mi = (ks * 3 + t) * NU + u;
-                                if (more && (mi * G) / TOT != ((mi + 1) * G) / TOT) dma_piece((mi * G) / TOT);
-                            }
-#endif
+                            constexpr int TOT = KS * 3 * NU;                       // one DMA piece after every (TOT / G)-th MFMA
+                            const int mi = (ks * 3 + t) * NU + u;
+                            if (more && (mi * G) / TOT != ((mi + 1) * G) / TOT) dma_piece((mi * G) / TOT);
                         }
-                } else {
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                TL_MARK(tl_comp);
+                // both groups pass the same number of barriers; group 1 skips its last one so that group 0 can start the
+                // epilogue early -- except with SPLIT, where group 1 still reads fragments from LDS in its last segment
+                if (SPLIT || !(grp == 1 && kc + 1 == k1)) __builtin_amdgcn_s_barrier();
+                TL_MARK(tl_b2);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+                nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+            }
+            // group 0 gets here one segment before group 1 (which reads no LDS in its last segment; the epilogue's LDS
+            // tiles are per wave)
+            if (SPLIT && grp == 0) __builtin_amdgcn_s_barrier();
+            if constexpr (SK) {
+                constexpr int PART = NT * MT * 16 * 64;                          // floats of one wave's accumulators
+                if (k0 > 0) {                                                    // tail part: hand the accumulators over
+                    float* w = p.ws + ((size_t)blockIdx.x * NW + wid) * PART + lane * 4;
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        const int i = u / MT, j = u % MT;
-                        acc[i][j] = mfma_unit<NP>(&frag[ks][i * NP], &frag[ks][NT * NP + j * NP], acc[i][j]);
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                *reinterpret_cast<f32x4*>(w + ((i * MT + j) * 4 + g) * 256) =
+                                    f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    // The two halves of a split tile run on the SAME XCD (workgroups b and b+8), i.e. behind the same L2:
+                    // once the stores have been acknowledged (vmcnt 0: the vector L1 is write-through) the partner can
+                    // read them -- no L2 write-back / invalidate (an agent-scope release/acquire pair costs ~60 us per
+                    // launch here).  The XCC id travels with the flag and is checked by the reader.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(p.wsflags + blockIdx.x, 1 + (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    it += k1 - k0; first_item = false;
+                    continue;
+                }
+                if (k1 < p.nk) {                                                 // head part: add the partner's tail, then finish
+                    const int partner = blockIdx.x + 8;                          // next workgroup of this XCD
+                    if (tid == 0) {
+                        int n = 0, f;
+                        while ((f = __hip_atomic_load(p.wsflags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++n < (1 << 22))
+                            __builtin_amdgcn_s_sleep(2);
+                        // never expected (reported by the host as an error): hand-over timed out, or the partner ran on
+                        // another XCD, whose L2 this one is not coherent with
+                        if ((f == 0 || f != 1 + (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15)) && p.flags) atomicOr(p.flags, 2);
+                        __hip_atomic_store(p.wsflags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    __syncthreads();
+                    const float* w = p.ws + ((size_t)partner * NW + wid) * PART + lane * 4;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 t = *reinterpret_cast<const f32x4*>(w + ((i * MT + j) * 4 + g) * 256);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += t[q];
+                            }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            TL_MARK(tl_comp);
-            if (!(grp == 1 && kc + 1 == p.nk)) __builtin_amdgcn_s_barrier();  // both groups pass 2*nk + 1 barriers
-            TL_MARK(tl_b2);
-            __builtin_amdgcn_sched_barrier(0);
-            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-            nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
-        }
-        // group 0 starts its epilogue while group 1 still computes (group 1 reads no LDS in its last segment and
-        // the epilogue's LDS tiles are per wave)
+            epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
+            TL_MARK(tl_epi);
 #ifdef YV3_TIMELINE
-        const unsigned long long tl_loop1 = __builtin_amdgcn_s_memtime();
+            ++tl_items; tl_chunks += k1 - k0;
 #endif
-        epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
+            it += k1 - k0; first_item = false;
+        }
 #ifdef YV3_TIMELINE
-        const unsigned long long tl_epi = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tl_drain = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 300 && lane == 0 && p.alpha) {     // debug build only: cycle split of one block -> alpha[0..]
+        if (blockIdx.x == 100 && lane == 0 && p.alpha) {     // debug build only: cycle split of one workgroup -> alpha[0..]
             float* dbg = const_cast<float*>(p.alpha) + wid * 8;
-            dbg[0] = (float)(tl_loop0 - tl_entry); dbg[1] = (float)tl_load; dbg[2] = (float)tl_b1; dbg[3] = (float)tl_comp;
-            dbg[4] = (float)tl_b2; dbg[5] = (float)(tl_epi - tl_loop1); dbg[6] = (float)(tl_drain - tl_epi); dbg[7] = (float)(tl_drain - tl_entry);
-            dbg[64] = (float)tl_l1; dbg[65] = (float)tl_l2; dbg[66] = (float)tl_l3;
+            dbg[0] = (float)tl_pro / tl_items; dbg[1] = (float)tl_load / tl_chunks; dbg[2] = (float)tl_b1 / tl_chunks;
+            dbg[3] = (float)tl_comp / tl_chunks; dbg[4] = (float)tl_b2 / tl_chunks; dbg[5] = (float)tl_epi / tl_items;
+            dbg[6] = (float)tl_items; dbg[7] = (float)(tl_t - tl_entry);
         }
 #endif
         return;
@@ -421,11 +482,29 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, hipStream
     const size_t epi = (size_t)WN * BM * (BN / WN + 4) * 4;   // WM*WN waves x (BM/WM) rows x (BN/WN + 4) floats
     const size_t lds = pipe > epi ? pipe : epi;
     static const bool use_pp = getenv("YV3_NO_PP") == nullptr;     // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
+    const bool use_sk = true;                                      // stream-K persistent schedule iff the caller gave a workspace
+    static const int num_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                   (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                                   return n >= 8 ? n & ~7 : 256; }();     // multiple of 8: equal workgroups per XCD
+    ConvParamsP q = p;
+    q.total = (int)grid.x;
+    // stream-K needs >= 1 tile per workgroup per XCD range (a tile is then split at most two ways) and the workspace.
+    // Opt-in (the caller passes yv3_conv_desc.workspace): a split tile is summed as head + tail, so its rounding
+    // depends on where the split falls, i.e. on the batch size / the image's position in the batch -- results stay
+    // within the parity tolerance but are no longer bit-identical across batch compositions.
+    // It is used only for launches of fewer than two rounds of tiles (the 13x13 layers): filling the idle CUs of a last
+    // partial round buys nothing on this power-limited kernel (the busy CUs simply clock higher: measured -9 % on the
+    // 2.6- and 5.3-round layers, which also lose the hardware's dynamic tile dispatch), but with 1.3 rounds the even
+    // split wins, and it lets the 13x13 3x3 layers use 256x128 tiles (+9 ... +11 %).
+    const bool sk = use_sk && p.ws && p.wsflags && q.total >= num_cu && q.total < 2 * num_cu && num_cu <= YV3_SK_MAX_WG &&
+                    p.ws_bytes >= yv3_conv_workspace_bytes();
+    const dim3 sgrid((unsigned)num_cu);
 #define YV3_LAUNCH(K3_, DUAL_, OF_) do { \
     if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3) { \
-        if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, p); break; } \
+        if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
+        if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
     } \
-    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_>), grid, block, lds, s, p); } while (0)
+    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_>), grid, block, lds, s, q); } while (0)
     if (out_f32) {
         if (k3 || dual) return YV3_ESHAPE;                   // fp32 outputs are the 1x1 head convs
         YV3_LAUNCH(false, false, true);
@@ -526,13 +605,16 @@ extern "C" int yv3_merge_planes(const void* in, float* out, long long n, int np,
 
 int yv3_conv2d_planes_k3s1(const ConvParamsP* pp, int np, int npad, long long M, hipStream_t s);
 
+extern "C" size_t yv3_conv_workspace_bytes(void) { return (size_t)YV3_SK_MAX_WG * (YV3_SK_PART_BYTES + sizeof(int)); }
+
 int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     ConvParamsP p;
     p.x = (const u16*)d->x; p.x2 = (const u16*)d->x2; p.w = (const u16*)d->w;
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const u16*)d->residual; p.y = d->y;
     p.H = d->H; p.W = d->W; p.Cin = d->cin; p.Cup = d->cin_up; p.Cout = d->cout;
     p.stride = d->stride; p.act = d->act; p.flags = d->flags;
-    { const char* e = getenv("YV3_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    p.ws = (float*)d->workspace; p.ws_bytes = d->workspace ? d->workspace_bytes : 0;
+    p.wsflags = d->workspace ? (int*)((char*)d->workspace + (size_t)YV3_SK_MAX_WG * YV3_SK_PART_BYTES) : nullptr;
     const int pad = (d->k - 1) / 2;
     p.Ho = (d->H + 2 * pad - d->k) / d->stride + 1;
     p.Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
@@ -569,7 +651,9 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // else 128x128 tiles (8 waves of 32x64) for finer granularity on the 13x13 / 26x26 layers
         const long long blocks256 = ((M + 255) / 256) * (npad / 128);
         p.ntiles = npad / 128;
-        if (blocks256 >= 512) return YV3_CFG(256, 128, 4, 2, 2);
+        // (with the stream-K schedule every CU gets the same share whatever the tile count: one tile per CU suffices)
+        const bool sk_ok = np == 2 && p.ws && !getenv("YV3_NO_PP");
+        if (blocks256 >= (sk_ok ? 256 : 512)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
     }
     if (npad % 64 == 0) { p.ntiles = npad / 64; return YV3_CFG(128, 64, 2, 2, 2); }

@@ -16,10 +16,17 @@ struct ConvParamsP {
     int Ho, Wo, M, K;
     int nk;                     // K / PBK
     int ntiles;
-    int stagger;                // first-round workgroups with (blockIdx>>3)&1 sleep stagger*1024 cycles before starting
+    int total;                  // workgroup tiles of the launch (m-tiles * ntiles)
+    float* ws;                  // stream-K workspace: YV3_SK_MAX_WG accumulator dumps, then YV3_SK_MAX_WG flags
+    int* wsflags;
+    size_t ws_bytes;
     int tb;                     // rows per packed weight tile
     int* flags;                 // optional: bit 0 <- an fp16-plane output was saturated
 };
+
+// stream-K workspace geometry (yv3_conv_workspace_bytes): one 512-thread workgroup's accumulators per CU + one flag
+#define YV3_SK_MAX_WG 512
+#define YV3_SK_PART_BYTES (512 * 64 * 4)
 
 namespace {
 
