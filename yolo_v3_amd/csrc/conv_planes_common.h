@@ -202,6 +202,20 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (OUT_F32) {
+        // fp32 logits of a head conv (cout = 255: rows are 1020 bytes, nothing is 16-byte aligned): consecutive lanes
+        // take consecutive channels, so every store instruction writes one or two contiguous row segments
+        static_assert(WTN <= 64 && 64 % WTN == 0, "one or more whole rows per store instruction");
+        constexpr int RPI = 64 / WTN;
+        float* yf = (float*)p.y;
+#pragma unroll 8
+        for (int r0 = 0; r0 < WTM; r0 += RPI) {
+            const int r = r0 + lane / WTN, c = lane % WTN;
+            const int m = m0 + wm * WTM + r, n = n0 + wn * WTN + c;
+            if (m < p.M && n < p.Cout) yf[(long long)m * p.Cout + n] = tile[r * EP + c];
+        }
+        return;
+    }
     float amax = 0.f;                                 // running max |v| of what this lane stores (fp16 range check)
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
