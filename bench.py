@@ -128,6 +128,7 @@ def main():
             lib = _ffi.lib()
             s = _ffi.stream_ptr()
             p0 = eng.packed[0]
+            plan.bind_detections(det.dets)                       # fused decode: the head convs write the detections
             _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
                                      plan.conv0_out.data_ptr(), B, plan.H, plan.W, codes[mode], plan.flags.data_ptr(), s))
             if timed:

@@ -123,6 +123,14 @@ typedef struct yv3_conv_desc {
                                are no longer bit-identical for the same image at different batch positions.
                                NULL: one tile per workgroup (bitwise batch-independent).                    */
     size_t workspace_bytes;
+    /* Fused YOLO decode (plane dtypes with out_dtype == YV3_F32 and cout == 3*(5+C) only): when dec_out is not
+       NULL the epilogue applies yv3_decode's map to the logits and writes the result to
+       dec_out + b*dec_out_batch_stride + (y*W+x)*cout + channel  (exactly what yv3_decode(logits = y, out = dec_out)
+       would write, bit for bit); `y` is then optional (NULL: the logits are not materialised). */
+    float*    dec_out;
+    long long dec_out_batch_stride;   /* floats */
+    float     dec_stride;             /* input pixels per grid cell (yololayer.py:36)            */
+    float     dec_anchors[6];         /* the 3 (w,h) anchor pairs of this scale, in input pixels */
 } yv3_conv_desc;
 
 /* Size of yv3_conv_desc.workspace. */

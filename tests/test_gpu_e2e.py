@@ -106,8 +106,12 @@ def test_conv_trunk_vs_oracle_layerwise(net, sw1_stream, mode):
     with torch.no_grad():
         oc.head_logits(sd, x, taps)
         eng = net.engine(mode)
-        _, plan = eng.forward(x.cuda())
-    torch.cuda.synchronize()
+        eng.fuse_decode, eng._plans = False, {}               # materialise the head convs' logits for this check
+        try:
+            _, plan = eng.forward(x.cuda())
+            torch.cuda.synchronize()
+        finally:
+            eng.fuse_decode, eng._plans = True, {}
     assert len(taps) == 75
     worst = 0.0
     for name, ref in taps:
@@ -335,3 +339,26 @@ def test_stream_k_schedule_end_to_end(golden_dir, sw1_stream):
     assert_close_rel(db, da.double(), TOL, "stream-K vs default schedule")      # two fp32-round-off paths, 75 layers deep
     ra, rb = detect(a, x), detect(b, x)
     assert [int(r.shape[0]) for r in ra] == [int(r.shape[0]) for r in rb]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [_ffi.F32X3, _ffi.F32H2, _ffi.BF16])
+def test_fused_decode_equals_separate_decode_bitwise(net, mode):
+    """The YOLO decode fused into the head convs' epilogue (default for the plane modes: the logits are never
+    written) produces bit-identical detections to head conv -> yv3_decode, at a 416 and a non-square size."""
+    for (B, H, W, seed) in ((3, 416, 416, 31), (2, 320, 480, 32)):
+        x = torch.from_numpy(synth.images(B, max(H, W), seed)[:, :, :H, :W].copy()).cuda()
+        eng = net.engine(mode)
+        net.img_dim = (W, H)
+        try:
+            eng.fuse_decode, eng._plans = True, {}
+            a, pa = eng.forward(x)
+            a = a.clone()
+            assert pa.fused_decode and all(lg is None for (lg, _, _) in pa.logits)
+            eng.fuse_decode, eng._plans = False, {}
+            b, pb = eng.forward(x)
+            assert not pb.fused_decode
+            assert torch.equal(a, b)
+        finally:
+            eng.fuse_decode, eng._plans = True, {}
+            net.img_dim = (416, 416)

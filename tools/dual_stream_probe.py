@@ -28,7 +28,7 @@ for L in (1, 2, 4):
         for i, st in enumerate(streams):
             st.wait_event(ev)
             with torch.cuda.stream(st):
-                eng.run_convs(plans[i], xs[i])
+                eng.run_convs(plans[i], xs[i], dets[i * sub:(i + 1) * sub])
                 eng.run_decode(plans[i], dets[i * sub:(i + 1) * sub])
             e = torch.cuda.Event(); e.record(st); main.wait_event(e)
     for _ in range(3): step()

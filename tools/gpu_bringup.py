@@ -84,7 +84,7 @@ if pieces:
         gr = torch.cuda.CUDAGraph()
         print("capturing", piece); sys.stdout.flush()
         with torch.cuda.graph(gr):
-            if piece == "convs": d.engine.run_convs(d.plan, st)
+            if piece == "convs": d.engine.run_convs(d.plan, st, d.dets)
             elif piece == "decode": d.engine.run_decode(d.plan, d.dets)
             elif piece == "filter": d.pp.filter(d.dets, 0.5, False, True)
             elif piece == "nms": d.pp.nms(d.dets, 0.4, True, d.pp.max_cand, d.pp.cap)

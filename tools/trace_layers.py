@@ -6,7 +6,7 @@ from yolo_v3_amd import arch
 path, B, size = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-convs = [r for r in rows if "conv_igemm" in r["Kernel_Name"] or "conv0_kernel" in r["Kernel_Name"] or "conv_planes" in r["Kernel_Name"]]
+convs = [r for r in rows if "conv_igemm" in r["Kernel_Name"] or "conv0_" in r["Kernel_Name"] or "conv_planes" in r["Kernel_Name"]]
 per_step = 75
 nsteps = len(convs) // per_step
 last = convs[(nsteps - 1) * per_step: nsteps * per_step]

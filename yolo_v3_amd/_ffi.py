@@ -25,7 +25,9 @@ class ConvDesc(ctypes.Structure):
                 ("B", c_int), ("H", c_int), ("W", c_int), ("cin", c_int), ("cin_up", c_int),
                 ("cout", c_int), ("cout_pad", c_int), ("k", c_int), ("stride", c_int), ("act", c_int),
                 ("dtype", c_int), ("out_dtype", c_int), ("flags", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("dec_out", c_void_p), ("dec_out_batch_stride", c_longlong), ("dec_stride", c_float),
+                ("dec_anchors", c_float * 6)]
 
 
 _SIGNATURES = {

@@ -18,7 +18,7 @@ extern "C" const char* yv3_error_string(int code) {
 }
 
 static int check_desc(const yv3_conv_desc* d) {
-    if (!d || !d->x || !d->w || !d->beta || !d->y) return YV3_EINVAL;
+    if (!d || !d->x || !d->w || !d->beta || (!d->y && !d->dec_out)) return YV3_EINVAL;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cin <= 0 || d->cout <= 0) return YV3_EINVAL;
     if (d->k != 1 && d->k != 3) return YV3_ESHAPE;
     if (d->stride != 1 && d->stride != 2) return YV3_ESHAPE;
@@ -36,6 +36,7 @@ extern "C" int yv3_conv2d(const yv3_conv_desc* d, void* stream) {
     if (rc) return rc;
     if (d->dtype == YV3_F32) {
         if (d->out_dtype != YV3_F32) return YV3_EDTYPE;
+        if (d->dec_out || !d->y) return YV3_EDTYPE;            // the fused decode lives in the plane kernels' epilogue
         return yv3_conv2d_f32(d, (hipStream_t)stream);
     }
     if (d->dtype == YV3_F32_BF16X3 || d->dtype == YV3_BF16 || d->dtype == YV3_F32_F16X2) {

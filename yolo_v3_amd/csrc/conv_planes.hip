@@ -613,6 +613,12 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const u16*)d->residual; p.y = d->y;
     p.H = d->H; p.W = d->W; p.Cin = d->cin; p.Cup = d->cin_up; p.Cout = d->cout;
     p.stride = d->stride; p.act = d->act; p.flags = d->flags;
+    p.dec_out = nullptr;
+    if (d->dec_out) {
+        if (d->out_dtype != YV3_F32 || d->cout % 3 || d->dec_stride <= 0.f) return YV3_ESHAPE;
+        p.dec_out = d->dec_out; p.dec_bs = d->dec_out_batch_stride; p.dec_stride = d->dec_stride;
+        for (int i = 0; i < 6; ++i) p.dec_an[i] = d->dec_anchors[i] / d->dec_stride;     // float32 division, as torch does
+    }
     p.ws = (float*)d->workspace; p.ws_bytes = d->workspace ? d->workspace_bytes : 0;
     p.wsflags = d->workspace ? (int*)((char*)d->workspace + (size_t)YV3_SK_MAX_WG * YV3_SK_PART_BYTES) : nullptr;
     const int pad = (d->k - 1) / 2;

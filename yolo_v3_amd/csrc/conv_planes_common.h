@@ -17,6 +17,9 @@ struct ConvParamsP {
     int nk;                     // K / PBK
     int ntiles;
     int total;                  // workgroup tiles of the launch (m-tiles * ntiles)
+    float* dec_out;             // fused YOLO decode of a head conv (yv3_conv_desc.dec_*); NULL: plain logits
+    long long dec_bs;
+    float dec_stride, dec_an[6]; // anchors already divided by the stride (w0,h0,w1,h1,w2,h2)
     float* ws;                  // stream-K workspace: YV3_SK_MAX_WG accumulator dumps, then YV3_SK_MAX_WG flags
     int* wsflags;
     size_t ws_bytes;
@@ -208,11 +211,34 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
         static_assert(WTN <= 64 && 64 % WTN == 0, "one or more whole rows per store instruction");
         constexpr int RPI = 64 / WTN;
         float* yf = (float*)p.y;
+        // fused decode (yv3_decode's map, yololayer.py:31-59,97-105): this lane's channel is fixed over the rows
+        const int nd = n0 + wn * WTN + lane % WTN;
+        const int attrib = p.Cout / 3;
+        const int anc = (nd >= attrib) + (nd >= 2 * attrib);
+        const int attr = nd - anc * attrib;
+        const float an = p.dec_an[(anc < 3 ? anc : 2) * 2 + (attr == 3 ? 1 : 0)];
+        // (image, grid y, grid x) of this lane's first row: two divisions once, then carried row by row
+        int db = 0, dgy = 0, dgx = 0;
+        if (p.dec_out) {
+            const int mf = m0 + wm * WTM + lane / WTN;
+            const int HoWo = p.Ho * p.Wo;
+            db = mf / HoWo;
+            const int pix = mf - db * HoWo;
+            dgy = pix / p.Wo; dgx = pix - dgy * p.Wo;
+        }
 #pragma unroll 8
         for (int r0 = 0; r0 < WTM; r0 += RPI) {
             const int r = r0 + lane / WTN, c = lane % WTN;
             const int m = m0 + wm * WTM + r, n = n0 + wn * WTN + c;
-            if (m < p.M && n < p.Cout) yf[(long long)m * p.Cout + n] = tile[r * EP + c];
+            if (m < p.M && n < p.Cout) {
+                const float t = tile[r * EP + c];
+                if (yf) yf[(long long)m * p.Cout + n] = t;
+                if (p.dec_out)
+                    p.dec_out[(long long)db * p.dec_bs + (long long)(dgy * p.Wo + dgx) * p.Cout + n] =
+                        yv3_decode_value(t, attr, an, (float)dgx, (float)dgy, p.dec_stride);
+            }
+            dgx += RPI;                                             // RPI <= 2 < Wo: at most one wrap per step
+            if (dgx >= p.Wo) { dgx -= p.Wo; if (++dgy == p.Ho) { dgy = 0; ++db; } }
         }
         return;
     }

@@ -21,8 +21,6 @@ struct DecodeArgs {
     float aw[3], ah[3];   // anchor / stride (float32 division, as torch does)
 };
 
-__device__ inline float sigmoidf_(float t) { return 1.f / (1.f + expf(-t)); }
-
 // One workgroup iteration = PPB consecutive pixels; thread -> channel ca of the 3*(5+C) per pixel (no
 // per-element integer division: anchor / attribute come from two compares, grid x/y once per pixel).
 constexpr int PPB = 4;
@@ -49,17 +47,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
             for (int k = 0; k < PPB; ++k) {
                 const int pix = p0 + k;
                 if (pix >= HW) break;
-                float v;
-                if (attr >= 4) {
-                    v = sigmoidf_(t[k]);
-                } else if (attr == 0) {
-                    v = (sigmoidf_(t[k]) + (float)(pix % a.W)) * a.stride;
-                } else if (attr == 1) {
-                    v = (sigmoidf_(t[k]) + (float)(pix / a.W)) * a.stride;
-                } else {
-                    v = (expf(t[k]) * an) * a.stride;
-                }
-                dst[(long long)pix * ch + ca] = v;
+                dst[(long long)pix * ch + ca] = yv3_decode_value(t[k], attr, an, (float)(pix % a.W), (float)(pix / a.W), a.stride);
             }
         }
     }

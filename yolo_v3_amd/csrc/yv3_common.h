@@ -37,3 +37,16 @@ __device__ static inline int yv3_xcd_remap(int bid, int nblk) {
     const int xcd = bid & 7, loc = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
+
+// YOLO decode of one logit (reference yololayer.py:31-59,97-105), shared by decode.hip and the fused head-conv
+// epilogue so that both produce the same bits.  attr: 0,1 = x,y; 2,3 = w,h; >= 4 = conf / class.
+//   xy : (sigmoid(t) + grid) * stride      wh : (exp(t) * (anchor / stride)) * stride      else : sigmoid(t)
+#ifdef __HIPCC__
+__device__ static inline float yv3_decode_value(float t, int attr, float an, float gx, float gy, float stride) {
+#pragma clang fp contract(off)
+    if (attr == 2 || attr == 3) return (expf(t) * an) * stride;
+    const float sg = 1.f / (1.f + expf(-t));
+    if (attr >= 4) return sg;
+    return (sg + (attr == 0 ? gx : gy)) * stride;
+}
+#endif

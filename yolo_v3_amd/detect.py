@@ -40,7 +40,7 @@ class Detector:
 
     # -- pipeline pieces (all asynchronous on the current stream)
     def _enqueue(self, x):
-        self.engine.run_convs(self.plan, x)
+        self.engine.run_convs(self.plan, x, self.dets)
         self.engine.run_decode(self.plan, self.dets)
         # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
         self.boxes, _ = self.pp.run_sync_free(self.dets, self.conf, self.nms_thr, self.is_eval, self.use_nms, prob=True)

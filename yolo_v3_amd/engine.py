@@ -160,12 +160,21 @@ class Plan:
             keep.append(t)
             return t
 
+        # the YOLO decode is fused into the three head convs' epilogue (plane kernels): their logits are then not
+        # materialised and the descriptors' dec_out is pointed at the caller's detections tensor before each launch
+        self.fused_decode = bool(engine.fuse_decode and dt != F32)
+        self.head_descs = []     # (descriptor index, ho, wo)
+
         def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
             pc = packed[i]
             ho, wo = out_hw(h, w, pc.spec.k, pc.spec.stride)
-            y = buf(ho, wo, pc.spec.cout, dt if out_dtype is None else out_dtype)
+            head = out_dtype == F32 and dt != F32
+            y = None if (head and self.fused_decode) else buf(ho, wo, pc.spec.cout, dt if out_dtype is None else out_dtype)
+            if head:
+                self.head_descs.append((len(descs), ho, wo))
             descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace))
-            self.layer_out[pc.spec.name] = y
+            if y is not None:
+                self.layer_out[pc.spec.name] = y
             return y, ho, wo
 
         # ---- backbone (reference darknet.py:72-88)
@@ -215,6 +224,7 @@ class Plan:
         self.rows = [hh * ww * 3 for (_, hh, ww) in self.logits]
         self.N = sum(self.rows)
         self.attrib = attrib
+        self._dets_ptr = None
         # decode parameters (yololayer.py:36-38): stride = H_img / nH, anchors by mask
         anchors = engine.anchors
         self.decode_args = []
@@ -225,6 +235,21 @@ class Plan:
                 flat += [float(anchors[2 * m]), float(anchors[2 * m + 1])]
             self.decode_args.append(((ctypes.c_float * 6)(*flat), float(H) / hh, row0, lg, hh, ww))
             row0 += hh * ww * 3
+        if self.fused_decode:
+            for (di, ho, wo), (anc, stride, r0, _, _, _) in zip(self.head_descs, self.decode_args):
+                d = self.descs[di]
+                d.dec_stride = stride
+                for k in range(6):
+                    d.dec_anchors[k] = anc[k]
+                d.dec_out_batch_stride = self.N * attrib
+
+    def bind_detections(self, dets):
+        """Point the fused head convs at `dets` ([B, N, 5+C] fp32, contiguous)."""
+        if not self.fused_decode or self._dets_ptr == dets.data_ptr():
+            return
+        for (di, _, _), (_, _, r0, _, _, _) in zip(self.head_descs, self.decode_args):
+            self.descs[di].dec_out = dets.data_ptr() + r0 * self.attrib * 4
+        self._dets_ptr = dets.data_ptr()
 
     def bytes_allocated(self):
         return sum(t.numel() * t.element_size() for t in self._keep)
@@ -247,6 +272,7 @@ class Engine:
         # stream-K schedule of the 13x13 layers (+1.7 % at 416x416 bs=64): opt-in, because a tile split between two
         # workgroups is summed in a batch-position-dependent order (include/yv3.h, yv3_conv_desc.workspace)
         self.stream_k = bool(getattr(net, "stream_k", os.environ.get("YV3_SK") == "1"))
+        self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
 
     # -- weights
     def _signature(self):
@@ -282,8 +308,14 @@ class Engine:
         return p
 
     # -- execution
-    def run_convs(self, plan, x):
+    def run_convs(self, plan, x, dets=None):
+        """conv0 + the 74-descriptor sequence.  With a fused-decode plan `dets` (the detections tensor the head
+        convs write) is required and `run_decode` is a no-op."""
         lib = _ffi.lib()
+        if plan.fused_decode:
+            if dets is None:
+                raise _ffi.Yv3Error("this plan decodes inside the head convs: pass the detections tensor to run_convs")
+            plan.bind_detections(dets)
         s = _ffi.stream_ptr()
         p0 = self.packed[0]
         _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
@@ -291,6 +323,8 @@ class Engine:
         _ffi.check(lib.yv3_conv2d_sequence(plan.descs, plan.n_desc, s), "yv3_conv2d_sequence")
 
     def run_decode(self, plan, dets):
+        if plan.fused_decode:
+            return
         lib = _ffi.lib()
         s = _ffi.stream_ptr()
         bstride = plan.N * plan.attrib
@@ -335,7 +369,7 @@ class Engine:
                 self.raise_if_overflowed(plan, int(plan.flags_host[0]))
             if dets is None:
                 dets = torch.empty((B, plan.N, plan.attrib), device=x.device, dtype=torch.float32)
-            self.run_convs(plan, x)
+            self.run_convs(plan, x, dets)
             self.run_decode(plan, dets)
             if self.dtype == F32H2:
                 plan.flags_host.copy_(plan.flags, non_blocking=True)
