@@ -34,7 +34,7 @@ for name in names:
     x = engine.to_planes(xf, dt)
     r = engine.to_planes(rf, dt) if res else None
     y = engine.alloc_act(B, ho, wo, cout, dt, "cuda")
-    ws = torch.zeros(lib.yv3_conv_workspace_bytes(), dtype=torch.uint8, device="cuda") if dt == _ffi.F32H2 else None
+    ws = torch.zeros(lib.yv3_conv_workspace_bytes(), dtype=torch.uint8, device="cuda") if (dt == _ffi.F32H2 and os.environ.get("SK") == "1") else None
     d = engine.make_desc(pc, x, y, B, H, H, r, dtype=dt, workspace=ws)
     st = _ffi.stream_ptr()
     for _ in range(3):

@@ -653,13 +653,16 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
                                          np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, s) : \
                                                    launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s))
     if (npad % 128 == 0) {
-        // 256x128 tiles (8 waves, 144 KB LDS) when they still give every CU >= 2 rounds of work,
-        // else 128x128 tiles (8 waves of 32x64) for finer granularity on the 13x13 / 26x26 layers
+        // 256x128 tiles (8 waves, 144 KB LDS; 64x64 per wave) from half a round of tiles upwards, else 128x128 tiles
+        // (8 waves of 32x64).  Measured at bs=64: the 13x13 layers have 172 / 344 big tiles (0.7 / 1.3 rounds) and are
+        // still 5 % (3x3) to 26 % (1x1) faster than with 340 / 680 small ones -- the big tile does 1/3 less LDS
+        // traffic per MFMA, and a partly filled round simply clocks higher on this power-limited kernel.
         const long long blocks256 = ((M + 255) / 256) * (npad / 128);
         p.ntiles = npad / 128;
         // (with the stream-K schedule every CU gets the same share whatever the tile count: one tile per CU suffices)
         const bool sk_ok = np == 2 && p.ws && !getenv("YV3_NO_PP");
-        if (blocks256 >= (sk_ok ? 256 : 512)) return YV3_CFG(256, 128, 4, 2, 2);
+        static const int big_min = getenv("YV3_BIG_MIN") ? atoi(getenv("YV3_BIG_MIN")) : 128;
+        if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
     }
     if (npad % 64 == 0) { p.ntiles = npad / 64; return YV3_CFG(128, 64, 2, 2, 2); }
