@@ -225,7 +225,11 @@ def main():
         if args.dtype in ("f32x3", "f32h2"):
             nm = {"f32x3": 6, "f32h2": 3}[args.dtype]
             out["roofline"]["note"] = ("achieved = algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense 16-bit MFMA / %d MFMAs per "
-                                       "fp32 product, so frac = matrix-pipe utilisation (%.0f TFLOP/s executed)" % (nm, nm * achieved))
+                                       "fp32 product, so frac = matrix-pipe utilisation (%.0f TFLOP/s executed); the kernel is "
+                                       "power-limited at ~1 PFLOP/s executed (DESIGN.md 3b)" % (nm, nm * achieved))
+            # the same fp32-class result against the roofline of doing it with fp32 MFMAs (157.3 TFLOP/s dense)
+            out["roofline"]["peak_fp32_mfma"] = PEAK_TFLOPS["f32"]
+            out["roofline"]["frac_vs_fp32_mfma_peak"] = round(achieved / PEAK_TFLOPS["f32"], 4)
         if secondary is not None:
             out["exact_fp32_mfma"] = secondary
         if world == 1 and not args.no_cpu_baseline:
