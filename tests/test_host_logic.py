@@ -121,7 +121,21 @@ def test_abi_exports_every_declared_symbol():
     assert b"workspace" in lib.yv3_error_string(-3)
     assert lib.yv3_postproc_cand_bytes(2, 100, 80) >= 2 * 100 * 8 + 2 * 80 * 4
     assert lib.yv3_postproc_nms_workspace_bytes(2, 128, 80) > 2 * 128 * (8 + 16 + 4 + 2) + 2 * 128 * 2 * 8
-    assert ctypes.sizeof(_ffi.ConvDesc) == 7 * 8 + 12 * 4 + 8
+    assert lib.yv3_conv_workspace_bytes() > 0
+
+
+def test_conv_desc_layout_matches_the_c_header(tmp_path):
+    """struct yv3_conv_desc as ctypes sees it == as a C compiler sees include/yv3.h (size and every field offset)."""
+    import subprocess
+    fields = [f for f, _ in _ffi.ConvDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "yv3.h"\nint main(void){printf("%zu", sizeof(yv3_conv_desc));\n'
+                   + "".join('printf(" %%zu", offsetof(yv3_conv_desc, %s));\n' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    nums = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_ffi.ConvDesc)
+    assert nums[1:] == [getattr(_ffi.ConvDesc, f).offset for f in fields]
 
 
 def test_no_cpu_fallback(sw1_stream):
