@@ -25,9 +25,6 @@
 
 namespace {
 
-#ifndef YV3_DIRECT_EPI
-#define YV3_DIRECT_EPI 0
-#endif
 #ifndef YV3_PP_GRP
 #define YV3_PP_GRP(wid) ((wid) >> 2)
 #endif
@@ -359,10 +356,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                             }
                 }
             }
-#if YV3_DIRECT_EPI
-            if constexpr (!OUT_F32) epilogue_store_direct<BM, BN, WM, WN>(acc, p, m0, n0, wid, lane);
-            else
-#endif
             epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
             TL_MARK(tl_epi);
 #ifdef YV3_TIMELINE

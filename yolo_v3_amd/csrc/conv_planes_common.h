@@ -303,112 +303,4 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     }
 }
 
-
-// ---- LDS-free epilogue of the fp16-plane kernels.  v_permlane32_swap exchanges, between the two half-waves, the
-// accumulator quads they hold of the same pixel, so that a lane ends up with two runs of 8 consecutive channels per
-// 32x32 MFMA tile (lower half: channels 0-7 and 8-15 of the tile, upper half: 16-23 and 24-31): residual planes are read
-// and output planes written as 16-byte pieces straight from registers.  A store instruction then covers 32 pixels x
-// two 16-byte pieces (the LDS-transposed epilogue writes 8 pixels x 128 contiguous bytes), but no LDS is touched, which
-// lets the pipeline stages of the NEXT tile fill while this runs.
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void epilogue_store_direct(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], const ConvParamsP& p,
-                                                      int m0, int n0, int wid, int lane) {
-    constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int MT = WTM / 32, NT = WTN / 32;
-    const int wm = wid / WN, wn = wid % WN;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const bool has_alpha = p.alpha != nullptr;
-    const float* asrc = has_alpha ? p.alpha : p.beta;
-    f32x4 alv[NT][2][2], bev[NT][2][2];                // [n-tile][octet][half]
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int n = n0 + wn * WTN + i * 32 + 8 * o + 16 * lhi;
-            const int nn = n < p.Cout ? n : 0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bev[i][o][h] = *reinterpret_cast<const f32x4*>(p.beta + nn + 4 * h);
-                alv[i][o][h] = *reinterpret_cast<const f32x4*>(asrc + nn + 4 * h);
-            }
-        }
-    u32x4 rres[NT][MT][2][2];                           // [n-tile][m-tile][octet][plane]
-    const bool has_res = p.res != nullptr;
-    if (has_res) {
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const int m = m0 + wm * WTM + j * 32 + l31;
-                    const int n = n0 + wn * WTN + i * 32 + 8 * o + 16 * lhi;
-                    const long long off = (m < p.M && n < p.Cout) ? (long long)m * p.Cout + n : 0;
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) rres[i][j][o][pl] = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + off);
-                }
-    }
-    if (!has_alpha) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) alv[i][o][h] = f32x4{1.f, 1.f, 1.f, 1.f};
-    }
-    const float slope = p.act == YV3_ACT_LEAKY ? 0.1f : 1.f;
-    float amax = 0.f;
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            // quads g and g+2 trade places between the half-waves (see above)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][4 * g + q]),
-                                                                    __float_as_uint(acc[i][j][4 * (g + 2) + q]), false, false);
-                    acc[i][j][4 * g + q] = __uint_as_float(r[0]);
-                    acc[i][j][4 * (g + 2) + q] = __uint_as_float(r[1]);
-                }
-            const int m = m0 + wm * WTM + j * 32 + l31;
-#pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                const int n = n0 + wn * WTN + i * 32 + 8 * o + 16 * lhi;
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float t0 = fmaf(acc[i][j][4 * o + q], alv[i][o][0][q], bev[i][o][0][q]);
-                    const float t1 = fmaf(acc[i][j][4 * (o + 2) + q], alv[i][o][1][q], bev[i][o][1][q]);
-                    v[q] = __builtin_fmaxf(t0, slope * t0);
-                    v[4 + q] = __builtin_fmaxf(t1, slope * t1);
-                }
-                if (has_res) {
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        const u32x4 q4 = rres[i][j][o][pl];
-#pragma unroll
-                        for (int h = 0; h < 4; ++h) { v[2 * h] += PlaneOps<2>::lo(q4[h]); v[2 * h + 1] += PlaneOps<2>::hi(q4[h]); }
-                    }
-                }
-                u32x4 qh, ql;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
-                    v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);
-                    v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
-                    qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
-                    ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
-                }
-                if (m < p.M && n < p.Cout) {
-                    u16* yo = (u16*)p.y + (long long)m * p.Cout + n;
-                    *reinterpret_cast<u32x4*>(yo) = qh;
-                    *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
-                }
-            }
-        }
-    if (p.flags && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.flags, 1);
-}
-
 }  // namespace
