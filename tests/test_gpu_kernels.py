@@ -243,11 +243,14 @@ def test_conv_bf16x3_split_vs_fp64(cin, cout, k, s, B, H, W, mode):
 
 
 @pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(512, 1024, 3, 1, 64, 13, 13), (1024, 512, 1, 1, 64, 13, 13), (256, 512, 3, 2, 50, 26, 26),
-                                                (512, 1024, 3, 1, 47, 13, 13)])
+                                                (512, 1024, 3, 1, 47, 13, 13), (512, 1024, 3, 1, 4, 13, 13), (256, 512, 3, 1, 1, 26, 26),
+                                                (128, 256, 3, 1, 1, 52, 52), (512, 1024, 3, 1, 1, 13, 13)])
 def test_conv_stream_k_schedule(cin, cout, k, s, B, H, W):
-    """Opt-in stream-K schedule (yv3_conv_desc.workspace) on launches of 1-2 rounds of tiles: every CU owns an equal
-    range of (tile, K-chunk) iterations; split tiles are finished by the workgroup holding the head part with the
-    accumulators its XCD neighbour left in the workspace.  Same fp32-class tolerance vs fp64 as the plain schedule,
+    """Opt-in stream-K schedule (yv3_conv_desc.workspace): every CU owns an equal range of (tile, K-chunk)
+    iterations; a split tile is finished by the workgroup holding its head part with the accumulators the following
+    workgroups of its XCD left in the workspace -- two-way splits on launches of 1-2 rounds of tiles, many-way splits
+    (a range shorter than a tile) when there are far fewer tiles than CUs; shapes outside the rule run the plain
+    schedule with the workspace ignored.  Same fp32-class tolerance vs fp64 as the plain schedule,
     the hand-over flags are all cleared again, no scheduling error is flagged, and a second launch reproduces the
     first bit for bit (the split points are a function of the shape only)."""
     mode = _ffi.F32H2

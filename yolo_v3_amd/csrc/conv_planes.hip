@@ -218,10 +218,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
         // are added in that fixed order and the epilogue runs once.  Ranges are >= nk chunks (host guarantees tiles >=
         // workgroups), so a tile is never split three ways.
         int it = 0, it_end = p.nk, tile_base = 0;
+        const int jb = blockIdx.x >> 3, nj = gridDim.x >> 3;                     // (SK) this workgroup's slot in its XCD
+        long long tx = 0;                                                        // (SK) chunk iterations of this XCD
         if constexpr (SK) {
-            const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nj = gridDim.x >> 3;
+            const int xcd = blockIdx.x & 7;
             const int t0 = (int)((long long)xcd * p.total / 8), t1 = (int)((long long)(xcd + 1) * p.total / 8);
-            const long long tx = (long long)(t1 - t0) * p.nk;
+            tx = (long long)(t1 - t0) * p.nk;
             it = (int)(tx * jb / nj); it_end = (int)(tx * (jb + 1) / nj); tile_base = t0;
         }
         bool first_item = true;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
             if (SPLIT && grp == 0) __builtin_amdgcn_s_barrier();
             if constexpr (SK) {
                 constexpr int PART = NT * MT * 16 * 64;                          // floats of one wave's accumulators
-                if (k0 > 0) {                                                    // tail part: hand the accumulators over
+                if (k0 > 0) {                                                    // tail / middle part: hand the accumulators over
                     float* w = p.ws + ((size_t)blockIdx.x * NW + wid) * PART + lane * 4;
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
@@ -331,29 +333,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
                     it += k1 - k0; first_item = false;
                     continue;
                 }
-                if (k1 < p.nk) {                                                 // head part: add the partner's tail, then finish
-                    const int partner = blockIdx.x + 8;                          // next workgroup of this XCD
-                    if (tid == 0) {
-                        int n = 0, f;
-                        while ((f = __hip_atomic_load(p.wsflags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++n < (1 << 22))
-                            __builtin_amdgcn_s_sleep(2);
-                        // never expected (reported by the host as an error): hand-over timed out, or the partner ran on
-                        // another XCD, whose L2 this one is not coherent with
-                        if ((f == 0 || f != 1 + (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15)) && p.flags) atomicOr(p.flags, 2);
-                        __hip_atomic_store(p.wsflags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k1 < p.nk) {
+                    // head part: add, in workgroup order, what the following workgroups of this XCD accumulated for the
+                    // rest of this tile (one tail part, preceded by middle parts when a range is shorter than a tile)
+                    const long long tile_end = (long long)(it / p.nk + 1) * p.nk;
+                    for (int k = 1; jb + k < nj; ++k) {
+                        const long long s_k = tx * (jb + k) / nj, e_k = tx * (jb + k + 1) / nj;
+                        if (s_k >= tile_end) break;
+                        if (e_k == s_k) continue;
+                        const int partner = blockIdx.x + 8 * k;
+                        if (tid == 0) {
+                            int n = 0, f;
+                            while ((f = __hip_atomic_load(p.wsflags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++n < (1 << 22))
+                                __builtin_amdgcn_s_sleep(2);
+                            // never expected (reported by the host as an error): hand-over timed out, or the partner ran
+                            // on another XCD, whose L2 this one is not coherent with
+                            if ((f == 0 || f != 1 + (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15)) && p.flags) atomicOr(p.flags, 2);
+                            __hip_atomic_store(p.wsflags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __syncthreads();
+                        const float* w = p.ws + ((size_t)partner * NW + wid) * PART + lane * 4;
+#pragma unroll
+                        for (int i = 0; i < NT; ++i)
+#pragma unroll
+                            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x4 t = *reinterpret_cast<const f32x4*>(w + ((i * MT + j) * 4 + g) * 256);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += t[q];
+                                }
                     }
-                    __syncthreads();
-                    const float* w = p.ws + ((size_t)partner * NW + wid) * PART + lane * 4;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-#pragma unroll
-                        for (int j = 0; j < MT; ++j)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const f32x4 t = *reinterpret_cast<const f32x4*>(w + ((i * MT + j) * 4 + g) * 256);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += t[q];
-                            }
                 }
             }
             epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
@@ -488,16 +498,21 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, hipStream
                                    return n >= 8 ? n & ~7 : 256; }();     // multiple of 8: equal workgroups per XCD
     ConvParamsP q = p;
     q.total = (int)grid.x;
-    // stream-K needs >= 1 tile per workgroup per XCD range (a tile is then split at most two ways) and the workspace.
-    // Opt-in (the caller passes yv3_conv_desc.workspace): a split tile is summed as head + tail, so its rounding
+    // stream-K: opt-in (the caller passes yv3_conv_desc.workspace): a split tile is summed as head + middle.. + tail, so its rounding
     // depends on where the split falls, i.e. on the batch size / the image's position in the batch -- results stay
     // within the parity tolerance but are no longer bit-identical across batch compositions.
-    // It is used only for launches of fewer than two rounds of tiles (the 13x13 layers): filling the idle CUs of a last
+    // It is used only for launches of fewer than two rounds of tiles (the 13x13 layers at bs=64; nearly every layer of a
+    // small batch, where it splits each tile's K range over the otherwise idle CUs): filling the idle CUs of a last
     // partial round buys nothing on this power-limited kernel (the busy CUs simply clock higher: measured -9 % on the
     // 2.6- and 5.3-round layers, which also lose the hardware's dynamic tile dispatch), but with 1.3 rounds the even
     // split wins, and it lets the 13x13 3x3 layers use 256x128 tiles (+9 ... +11 %).
-    const bool sk = use_sk && p.ws && p.wsflags && q.total >= num_cu && q.total < 2 * num_cu && num_cu <= YV3_SK_MAX_WG &&
-                    p.ws_bytes >= yv3_conv_workspace_bytes();
+    // Measured rule (tools/conv_bench.py, bs = 4 ... 64): it pays for the long-K 3x3 layers when the tiles fill 1 - 2
+    // rounds (even split instead of a 30 - 100 % idle second round) or at most 0.4 rounds (each tile's K range spread
+    // over the idle CUs: the 13x13 3x3 layer at bs=4 0.084 -> 0.039 ms); it loses for 1x1 layers (the accumulator
+    // exchange outweighs their few K chunks) and around 0.7 rounds.
+    const bool sk_shape = k3 && ((q.total >= num_cu && q.total < 2 * num_cu) || 5 * q.total <= 2 * num_cu);
+    const bool sk = use_sk && p.ws && p.wsflags && sk_shape && (long long)q.total * p.nk >= num_cu &&
+                    num_cu <= YV3_SK_MAX_WG && p.ws_bytes >= yv3_conv_workspace_bytes();
     const dim3 sgrid((unsigned)num_cu);
 #define YV3_LAUNCH(K3_, DUAL_, OF_) do { \
     if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3) { \
