@@ -362,3 +362,20 @@ def test_fused_decode_equals_separate_decode_bitwise(net, mode):
         finally:
             eng.fuse_decode, eng._plans = True, {}
             net.img_dim = (416, 416)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stream_k", [False, True])
+def test_odd_shapes_vs_oracle(sw1_stream, stream_k):
+    """Whole-net detections vs the CPU oracle on batch sizes / image sizes that exercise every tile configuration's
+    tails (M not a multiple of any tile, non-square grids, a grid smaller than one tile), for both schedules."""
+    sd, _ = oc.state_dict_from_stream(sw1_stream)
+    net = load_sw1_net(sw1_stream).cuda()
+    net.stream_k = stream_k
+    for (B, H, W) in [(3, 320, 320), (5, 352, 608), (2, 96, 64), (9, 224, 416)]:
+        net.img_dim = (W, H)
+        x = torch.from_numpy(synth.images(B, max(H, W), 100 + B)[:, :, :H, :W].copy())
+        with torch.no_grad():
+            got = net.forward_cat(x.cuda()).cpu()
+            ref = torch.cat(oc.yolonet_forward(sd, x), 1)
+        assert_close_rel(got, ref.double(), TOL, "B=%d %dx%d stream_k=%d" % (B, H, W, stream_k))
