@@ -131,7 +131,16 @@ typedef struct yv3_conv_desc {
     long long dec_out_batch_stride;   /* floats */
     float     dec_stride;             /* input pixels per grid cell (yololayer.py:36)            */
     float     dec_anchors[6];         /* the 3 (w,h) anchor pairs of this scale, in input pixels */
+    /* Kernel-selection overrides (tuning / A-B measurements; 0 = the library's defaults).  They live in the
+       descriptor -- not in environment variables or other process-global state -- so concurrent callers cannot
+       affect each other. */
+    unsigned  options;                /* OR of YV3_OPT_*                                          */
+    int       big_tile_min;           /* plane kernels: minimum number of 256x128 tiles for which that tile is
+                                         used instead of 128x128 (0: default 128 = half a round of the chip) */
 } yv3_conv_desc;
+
+#define YV3_OPT_NO_PINGPONG 1u    /* fp16-plane 8-wave tiles: single-phase main loop instead of the two-group ping-pong */
+#define YV3_OPT_K3S1        2u    /* 3x3 stride-1 plane convs: the kw-tap-reuse kernel (conv_planes_k3s1.hip)          */
 
 /* Size of yv3_conv_desc.workspace. */
 size_t yv3_conv_workspace_bytes(void);

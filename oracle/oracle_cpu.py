@@ -82,29 +82,49 @@ def state_dict_from_stream(stream, num_class=80):
 
 
 # --------------------------------------------------------------------------- conv trunk
-def cbr(sd, prefix, x, stride=1):
+# ``prec`` selects the arithmetic the conv trunk is restated in:
+#   None    the reference as it runs: fp32 everywhere (darknet.py:43-44,52-53,118)
+#   "bf16"  BASELINE configs[2] "bf16 convs / fp32 decode": the SAME reference ops with every conv's operands
+#           rounded to bfloat16 (round-to-nearest-even) -- the weights of every conv except the 3-channel first
+#           layer, and every STORED activation, i.e. the output of each conv_bn_relu (after BN + LeakyReLU,
+#           darknet.py:43-44), of each res_layer (after the fp32 add, darknet.py:52-53) and of UpsampleGroup's
+#           conv -- with fp32 accumulation, fp32 BN/activation/residual add, fp32 head logits (darknet.py:118),
+#           fp32 decode and post-processing.  A bf16 x bf16 product is exact in fp32, so the only difference
+#           between two implementations of this definition is the fp32 summation order.  Pinned by running the
+#           reference's own modules with rounding hooks (oracle/make_golden_bf16.py -> tests/golden/e2e_bf16.npz).
+def round_bf16(t):
+    """fp32 -> nearest bfloat16 (ties to even) -> fp32."""
+    return t.bfloat16().float()
+
+
+def cbr(sd, prefix, x, stride=1, prec=None, store=True):
     """reference darknet.py:27-44: conv(no bias, pad=(k-1)//2) -> BatchNorm2d(eval) -> LeakyReLU(0.1)."""
     w = sd[prefix + ".conv.weight"]
+    if prec == "bf16" and w.shape[1] != 3:
+        w = round_bf16(w)
     y = F.conv2d(x, w, None, stride, (w.shape[2] - 1) // 2)
     y = F.batch_norm(y, sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"],
                      sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], False, 0.1, 1e-5)
-    return F.leaky_relu(y, 0.1)
+    y = F.leaky_relu(y, 0.1)
+    return round_bf16(y) if (prec == "bf16" and store) else y
 
 
-def backbone(sd, x, taps=None):
+def backbone(sd, x, taps=None, prec=None):
     """reference darknet.py:72-88 + 46-53.  Returns (out, route36 [52x52x256], route61 [26x26x512])."""
-    x = cbr(sd, "feature.mlist.0", x)
+    x = cbr(sd, "feature.mlist.0", x, prec=prec)
     if taps is not None: taps.append(("feature.mlist.0", x))
     idx, routes = 1, {}
     for nblk in BLOCKS:
-        x = cbr(sd, "feature.mlist.%d" % idx, x, stride=2)
+        x = cbr(sd, "feature.mlist.%d" % idx, x, stride=2, prec=prec)
         if taps is not None: taps.append(("feature.mlist.%d" % idx, x))
         idx += 1
         for _ in range(nblk):
             p = "feature.mlist.%d" % idx
-            h = cbr(sd, p + ".conv1", x)
+            h = cbr(sd, p + ".conv1", x, prec=prec)
             if taps is not None: taps.append((p + ".conv1", h))
-            x = x + cbr(sd, p + ".conv2", h)                       # darknet.py:53
+            x = x + cbr(sd, p + ".conv2", h, prec=prec, store=False)   # darknet.py:53 (the sum is what is stored)
+            if prec == "bf16":
+                x = round_bf16(x)
             if taps is not None: taps.append((p + ".conv2", x))
             idx += 1
         routes[idx - 1] = x
@@ -112,33 +132,34 @@ def backbone(sd, x, taps=None):
     return x, routes[14], routes[23]
 
 
-def predet(sd, prefix, x, taps=None):
+def predet(sd, prefix, x, taps=None, prec=None):
     """reference darknet.py:107-127.  Returns (head logits NCHW, output of mlist[4])."""
     route = None
     for i in range(6):
-        x = cbr(sd, "%s.mlist.%d" % (prefix, i), x)
+        x = cbr(sd, "%s.mlist.%d" % (prefix, i), x, prec=prec)
         if taps is not None: taps.append(("%s.mlist.%d" % (prefix, i), x))
         if i == 4:
             route = x                                               # darknet.py:185 addCachedOut(-3)
-    logits = F.conv2d(x, sd[prefix + ".mlist.6.weight"], sd[prefix + ".mlist.6.bias"])
+    w = sd[prefix + ".mlist.6.weight"]
+    logits = F.conv2d(x, round_bf16(w) if prec == "bf16" else w, sd[prefix + ".mlist.6.bias"])   # fp32 logits
     if taps is not None: taps.append((prefix + ".mlist.6", logits))
     return logits, route
 
 
-def upsample_cat(sd, prefix, head, tail, taps=None):
+def upsample_cat(sd, prefix, head, tail, taps=None, prec=None):
     """reference darknet.py:159-162: 1x1 cbr, nearest x2, cat((up, tail), dim=1)."""
-    out = cbr(sd, prefix + ".conv", head)
+    out = cbr(sd, prefix + ".conv", head, prec=prec)
     if taps is not None: taps.append((prefix + ".conv", out))
     out = F.interpolate(out, scale_factor=2, mode="nearest")
     return torch.cat((out, tail), 1)
 
 
-def head_logits(sd, x, taps=None):
+def head_logits(sd, x, taps=None, prec=None):
     """Conv trunk only: the three head logit maps [B,255,h,w] (reference darknet.py:198-223)."""
-    feat, r36, r61 = backbone(sd, x, taps)
-    l1, h1 = predet(sd, "pre_det1", feat, taps)
-    l2, h2 = predet(sd, "pre_det2", upsample_cat(sd, "up1", h1, r61, taps), taps)
-    l3, _ = predet(sd, "pre_det3", upsample_cat(sd, "up2", h2, r36, taps), taps)
+    feat, r36, r61 = backbone(sd, x, taps, prec)
+    l1, h1 = predet(sd, "pre_det1", feat, taps, prec)
+    l2, h2 = predet(sd, "pre_det2", upsample_cat(sd, "up1", h1, r61, taps, prec), taps, prec)
+    l3, _ = predet(sd, "pre_det3", upsample_cat(sd, "up2", h2, r36, taps, prec), taps, prec)
     return l1, l2, l3
 
 
@@ -172,10 +193,10 @@ def decode(x, anchors_all, anchors_mask, img_dim, num_class=80):
     return out.permute(0, 2, 3, 1, 4).contiguous().view(nB, nA * nH * nW, attrib)   # :104
 
 
-def yolonet_forward(sd, x, anchors=DEFAULT_ANCHORS, num_class=80):
+def yolonet_forward(sd, x, anchors=DEFAULT_ANCHORS, num_class=80, prec=None):
     """reference darknet.py:198-231 with target=None: returns (det1, det2, det3)."""
     img_dim = (x.shape[3], x.shape[2])                               # darknet.py:199
-    l1, l2, l3 = head_logits(sd, x)
+    l1, l2, l3 = head_logits(sd, x, prec=prec)
     return (decode(l1, anchors, (6, 7, 8), img_dim, num_class),
             decode(l2, anchors, (3, 4, 5), img_dim, num_class),
             decode(l3, anchors, (0, 1, 2), img_dim, num_class))
@@ -281,10 +302,10 @@ def postprocess(detections, num_classes, obj_conf_thr=0.5, nms_thr=0.4, is_eval=
 
 
 def detect(sd, imgs, num_classes=80, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
-           anchors=DEFAULT_ANCHORS):
+           anchors=DEFAULT_ANCHORS, prec=None):
     """The caller idiom of reference test.py:35-36 / evaluate.py:201-204."""
     with torch.no_grad():
-        d1, d2, d3 = yolonet_forward(sd, imgs, anchors, num_classes)
+        d1, d2, d3 = yolonet_forward(sd, imgs, anchors, num_classes, prec)
         return postprocess(torch.cat((d1, d2, d3), 1), num_classes, obj_conf_thr, nms_thr, is_eval, use_nms)
 
 

@@ -35,6 +35,33 @@ def _worker(rank, world, port, q):
         ok = ok and bool((ab[img, :n, 0] == float(img) + torch.arange(n) / 10.0).all())
     lst = ydist.boxes_to_list(ab, ac)
     ok = ok and len(lst) == B * world and lst[0].shape == (0,) and lst[1].shape == (1, 7)
+    # the sharded-detect plumbing around the single-GPU pipeline (dist.detect_sharded): UNEVEN split of a global
+    # batch of 5 over 2 ranks, padded shards, one all-gather, padding dropped, reference result convention
+    Bg, cap2 = 5, 4
+    imgs = torch.arange(Bg, dtype=torch.float32).view(Bg, 1, 1, 1).expand(Bg, 3, 2, 2).contiguous()     # image id in every pixel
+    x, b_pad, spans = ydist.take_shard(imgs, rank, world)
+    ok = ok and b_pad == 3 and spans == [(0, 3), (3, 5)] and x.shape[0] == 3
+    ids = x[:, 0, 0, 0].to(torch.int64)                                 # what this rank "detects": image g keeps g % 3 boxes
+    bx = torch.zeros(b_pad, cap2, 7)
+    meta = torch.zeros(b_pad, 3, dtype=torch.int32)
+    for i, g in enumerate(ids.tolist()):
+        n = g % 3
+        meta[i, 0], meta[i, 1] = n, n
+        bx[i, :n, 0] = float(g)
+        bx[i, :n, 6] = torch.arange(n, dtype=torch.float32)
+    gb, gm = ydist.gather_boxes(bx, meta.view(-1))
+    res, status = ydist.assemble_global(gb, gm, spans, b_pad, max_cand=10, cap=cap2)
+    ok = ok and status == 0 and len(res) == Bg
+    for g in range(Bg):
+        n = g % 3
+        ok = ok and (tuple(res[g].shape) == ((n, 7) if n else (0,)))
+        ok = ok and (n == 0 or bool((res[g][:, 0] == float(g)).all()))
+    # nothing anywhere -> the [] sentinel; a status bit set on ONE rank is seen by all
+    meta0 = torch.zeros(b_pad, 3, dtype=torch.int32)
+    meta0[:, 2] = rank                                                  # rank 1 reports status 1
+    gb, gm = ydist.gather_boxes(torch.zeros(b_pad, cap2, 7), meta0.view(-1))
+    res0, status0 = ydist.assemble_global(gb, gm, spans, b_pad, 10, cap2)
+    ok = ok and res0 == [] and status0 == 1
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -106,3 +106,61 @@ def test_neighbour_rows_bitwise_vs_reference(golden_dir):
             out = oc.correct_yolo_boxes(boxes, ow, oh, iw, ih, bool(lb))
             assert np.array_equal(out.numpy(), g["out_%d_%d" % (ci, lb)]), (ci, lb)
         assert np.array_equal(np.array(oc.letterbox_transforms((ow, oh), (iw, ih)), dtype=np.float64), g["trans_%d" % ci])
+
+
+def test_bf16_restatement_vs_hooked_reference(golden_dir, sw1_stream):
+    """BASELINE configs[2] ("bf16 convs / fp32 decode"): oracle_cpu's ``prec="bf16"`` restatement equals, BIT FOR BIT,
+    what the reference's own modules produce when their conv operands are rounded to bfloat16 by forward hooks
+    (oracle/make_golden_bf16.py -> tests/golden/e2e_bf16.npz)."""
+    g = np.load(os.path.join(golden_dir, "e2e_bf16.npz"))
+    sd, _ = oc.state_dict_from_stream(sw1_stream)
+    for name in ("u416", "u608"):
+        B, size, seed = [int(v) for v in g[name + "_cfg"]]
+        x = torch.from_numpy(synth.images(B, size, seed))
+        with torch.no_grad():
+            d = torch.cat(oc.yolonet_forward(sd, x, prec="bf16"), 1)
+        assert np.array_equal(d[:, g[name + "_rows"]].numpy(), g[name + "_dets_rows"]), name
+        s, m = g[name + "_dets_sum"]
+        assert abs(float(d.double().sum()) - s) <= 1e-9 * abs(s) and float(d.double().abs().max()) == m
+        # and it is a different computation from the fp32 path (mean |d|/max(1,|ref|) ~ 1.4e-3)
+        with torch.no_grad():
+            f = torch.cat(oc.yolonet_forward(sd, x), 1)
+        e = ((d - f).abs() / f.abs().clamp(min=1.0)).mean()
+        assert 2e-4 < float(e) < 1e-2
+
+
+def test_boxes_delta_metric():
+    """oracle/boxdelta.py: the 'NMS boxes delta vs ref' figure (set-wise pairing within image and class)."""
+    from oracle.boxdelta import boxes_delta
+    a = [torch.tensor([[0, 0, 10, 10, .9, .8, 3.], [5, 5, 20, 20, .9, .7, 3.], [0, 0, 5, 5, .5, .6, 1.]]), torch.Tensor()]
+    b = [torch.tensor([[5, 5, 20, 20.001, .9, .7, 3.], [0, 0, 10, 10, .9, .8001, 3.]]), torch.Tensor()]
+    d = boxes_delta(a, b)
+    assert (d["images"], d["ref_boxes"], d["got_boxes"], d["matched"], d["unmatched_got"], d["unmatched_ref"]) == (2, 2, 3, 2, 1, 0)
+    assert d["count_equal_images"] == 1 and d["class_equal_images"] == 1 and abs(d["unmatched_frac"] - 0.2) < 1e-12
+    assert 4e-5 < d["max_rel_err_coords"] < 6e-5 and 0.9e-4 < d["max_abs_err_score"] < 1.1e-4 and d["max_abs_err_conf"] == 0.0
+    z = boxes_delta([], [], n_img=3)
+    assert z["unmatched_frac"] == 0.0 and z["count_equal_images"] == 3
+    same = boxes_delta(a, a)
+    assert same["matched"] == 3 and same["max_rel_err_coords"] == 0.0 and same["min_matched_iou"] == 1.0
+
+
+def test_eval_mode_at_reference_thresholds_vs_reference(golden_dir):
+    """evaluate.py:201-204 as the reference runs it (conf 0.005 / nms 0.45 / is_eval=True) with the SW-eval weights:
+    the oracle's detections and kept boxes equal the reference's (oracle/make_golden_eval.py)."""
+    g = np.load(os.path.join(golden_dir, "e2e_eval.npz"))
+    B, size, seed = [int(v) for v in g["in_cfg"]]
+    ct, nt = [float(v) for v in g["cfg"]]
+    assert (ct, nt) == (0.005, 0.45)
+    sd, _ = oc.state_dict_from_stream(synth.eval_weight_stream())
+    x = torch.from_numpy(synth.images(B, size, seed))
+    with torch.no_grad():
+        dets = torch.cat(oc.yolonet_forward(sd, x), 1)
+    assert np.abs(dets[:, g["rows"]].numpy() - g["dets_rows"]).max() <= 2e-6 * max(1.0, float(np.abs(g["dets_rows"]).max()))
+    sc = dets[..., 5:] * dets[..., 4:5]
+    assert (sc > ct).sum((1, 2)).tolist() == g["n_pairs"].tolist() and 1000 <= int(g["n_pairs"].min()) <= 3000
+    res = oc.postprocess(dets, 80, ct, nt, True, True)
+    for i, r in enumerate(res):
+        exp = g["boxes%d" % i]
+        assert tuple(r.shape) == tuple(exp.shape)
+        assert np.abs(r.numpy() - exp).max() <= 1e-4
+        assert np.array_equal(r.numpy()[:, 6], exp[:, 6])

@@ -4,7 +4,9 @@ FETCH_SIZE counts 64 B per 128-B request for wide streaming reads, i.e. it must 
 (guide section "HBM").  Both the raw and the corrected figure are printed."""
 import csv, sys, json, collections
 def load(d):
-    rows = list(csv.DictReader(open(d + "/t_counter_collection.csv")))
+    import glob, os
+    hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    rows = list(csv.DictReader(open(hits[0])))
     per = collections.OrderedDict()
     for r in rows:
         per.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], 0.0])[1] += float(r["Counter_Value"])

@@ -18,5 +18,6 @@ from .utils import (postprocessing, iou_vectorized, bbox_iou, PostProcessor, let
                     letterbox_batch, letterbox_image, load_image)
 from .boundingbox import bbox_cxcywh_to_x1y1x2y2, correct_yolo_boxes, letterbox_reverse, rescale_bbox   # noqa: F401
 from .detect import detect, Detector, predict  # noqa: F401
+from .dist import detect_sharded                # noqa: F401
 
 __version__ = "0.1.0"

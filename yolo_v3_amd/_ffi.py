@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("YV3_LIB") or os.path.join(_HERE, "libyv3.so")     # Y
 F32, BF16, F32X3, F32H2 = 0, 1, 2, 3
 ACT_LINEAR, ACT_LEAKY = 0, 1
 PP_EVAL, PP_PROB = 1, 2
+OPT_NO_PINGPONG, OPT_K3S1 = 1, 2
 
 c_void_p, c_int, c_float, c_size_t, c_longlong = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_size_t, ctypes.c_longlong)
@@ -27,7 +28,7 @@ class ConvDesc(ctypes.Structure):
                 ("dtype", c_int), ("out_dtype", c_int), ("flags", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("dec_out", c_void_p), ("dec_out_batch_stride", c_longlong), ("dec_stride", c_float),
-                ("dec_anchors", c_float * 6)]
+                ("dec_anchors", c_float * 6), ("options", ctypes.c_uint), ("big_tile_min", c_int)]
 
 
 _SIGNATURES = {

@@ -1,4 +1,5 @@
 """Drop-in surface of the part of the reference's ``boundingbox.py`` that is on the hot path."""
+import numpy as np
 import torch
 
 from . import _ffi
@@ -26,7 +27,7 @@ def _unmap(labels, org_w, org_h, new_w, new_h, is_letterbox, xyxy):
     """Shared GPU path of letterbox_reverse / rescale_bbox / correct_yolo_boxes for a [n, >=4] tensor (CPU or
     GPU; the result follows the input device): un-mapped + clipped x1y1x2y2 (xyxy=True) or xywh."""
     if not isinstance(labels, torch.Tensor):
-        raise TypeError("Labels must be a pytorch tensor")
+        raise TypeError("Labels must be a numpy array or pytorch tensor")
     was_cpu = not labels.is_cuda
     if was_cpu and not torch.cuda.is_available():
         raise _ffi.Yv3Error("no GPU available: this package has no CPU path")
@@ -50,19 +51,27 @@ def correct_yolo_boxes(bboxes, org_w, org_h, img_w, img_h, is_letterbox=False):
     return _unmap(bboxes[..., :4], org_w, org_h, img_w, img_h, is_letterbox, False)
 
 
-def letterbox_reverse(labels, org_w, org_h, new_w, new_h):
-    """reference boundingbox.py:95-116: undo the letterbox mapping on columns 0..3 (x1,y1,x2,y2), clip to the image."""
+def _unmap_labels(labels, org_w, org_h, new_w, new_h, is_letterbox):
+    """torch tensors and numpy arrays alike (the reference accepts both, boundingbox.py:99-104); a copy is returned."""
     if len(labels) == 0:
         return labels
+    if isinstance(labels, np.ndarray):
+        out = labels.copy()
+        out[..., :4] = _unmap(torch.from_numpy(np.ascontiguousarray(labels[..., :4], dtype=np.float32)),
+                              org_w, org_h, new_w, new_h, is_letterbox, True).numpy()
+        return out
+    if not isinstance(labels, torch.Tensor):
+        raise TypeError("Labels must be a numpy array or pytorch tensor")
     out = labels.clone()
-    out[..., :4] = _unmap(labels[..., :4], org_w, org_h, new_w, new_h, True, True)
+    out[..., :4] = _unmap(labels[..., :4], org_w, org_h, new_w, new_h, is_letterbox, True)
     return out
+
+
+def letterbox_reverse(labels, org_w, org_h, new_w, new_h):
+    """reference boundingbox.py:95-116: undo the letterbox mapping on columns 0..3 (x1,y1,x2,y2), clip to the image."""
+    return _unmap_labels(labels, org_w, org_h, new_w, new_h, True)
 
 
 def rescale_bbox(labels, org_w, org_h, new_w, new_h):
     """reference boundingbox.py:119-137: undo a plain resize on columns 0..3 (x1,y1,x2,y2), clip to the image."""
-    if len(labels) == 0:
-        return labels
-    out = labels.clone()
-    out[..., :4] = _unmap(labels[..., :4], org_w, org_h, new_w, new_h, False, True)
-    return out
+    return _unmap_labels(labels, org_w, org_h, new_w, new_h, False)

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
                          void* y_nhwc, int B, int H, int W, int out_dtype, int* flags, void* stream) {
     if (!x_nchw || !w_tap_major || !alpha || !beta || !y_nhwc || B <= 0 || H <= 0 || W <= 0) return YV3_EINVAL;
-    if (out_dtype == YV3_F32_F16X2 && !getenv("YV3_CONV0_VALU")) {
+    if (out_dtype == YV3_F32_F16X2) {
         const dim3 g((unsigned)yv3_ceil_div(W, C0_TC), (unsigned)yv3_ceil_div(H, C0_TR), (unsigned)B);
         hipLaunchKernelGGL(conv0_mfma_kernel, g, dim3(256), 0, (hipStream_t)stream, x_nchw, w_tap_major, alpha, beta,
                            (u16*)y_nhwc, H, W, (long long)B * H * W * 32, flags);
@@ -240,8 +240,6 @@ extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const fl
         hipLaunchKernelGGL(conv0_kernel<1>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else if (out_dtype == YV3_F32_BF16X3)
         hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
-    else if (out_dtype == YV3_F32_F16X2)
-        hipLaunchKernelGGL(conv0_kernel<2>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else
         return YV3_EDTYPE;
     YV3_CHECK_LAUNCH();

@@ -484,18 +484,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
 }
 
 template <int NP, int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, hipStream_t s) {
+int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_pp, hipStream_t s) {
     const int mtiles = (p.M + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
     const dim3 block(64 * WM * WN);
     const size_t pipe = (size_t)NSTAGE * NP * (BM + BN) * ROWB;
     const size_t epi = (size_t)WN * BM * (BN / WN + 4) * 4;   // WM*WN waves x (BM/WM) rows x (BN/WN + 4) floats
     const size_t lds = pipe > epi ? pipe : epi;
-    static const bool use_pp = getenv("YV3_NO_PP") == nullptr;     // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
     const bool use_sk = true;                                      // stream-K persistent schedule iff the caller gave a workspace
-    static const int num_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
-                                   (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-                                   return n >= 8 ? n & ~7 : 256; }();     // multiple of 8: equal workgroups per XCD
+    const int num_cu = yv3_num_cu();                               // of the CURRENT device; multiple of 8: equal workgroups per XCD
     ConvParamsP q = p;
     q.total = (int)grid.x;
     // stream-K: opt-in (the caller passes yv3_conv_desc.workspace): a split tile is summed as head + middle.. + tail, so its rounding
@@ -660,13 +657,14 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
     // kw-tap reuse kernel (conv_planes_k3s1.hip): 44 % less L2->LDS traffic, same results, but no faster on
     // MI355X because this MFMA stream is power-limited -- opt-in until that changes.
-    if (k3 && d->stride == 1 && !out_f32 && getenv("YV3_K3S1")) {
+    if (k3 && d->stride == 1 && !out_f32 && (d->options & YV3_OPT_K3S1)) {
         const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
         if (rc != -100) return rc;
     }
-#define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s) : \
-                                         np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, s) : \
-                                                   launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, s))
+    const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
+#define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
+                                         np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, use_pp, s) : \
+                                                   launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s))
     if (npad % 128 == 0) {
         // 256x128 tiles (8 waves, 144 KB LDS; 64x64 per wave) from half a round of tiles upwards, else 128x128 tiles
         // (8 waves of 32x64).  Measured at bs=64: the 13x13 layers have 172 / 344 big tiles (0.7 / 1.3 rounds) and are
@@ -675,8 +673,8 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const long long blocks256 = ((M + 255) / 256) * (npad / 128);
         p.ntiles = npad / 128;
         // (with the stream-K schedule every CU gets the same share whatever the tile count: one tile per CU suffices)
-        const bool sk_ok = np == 2 && p.ws && !getenv("YV3_NO_PP");
-        static const int big_min = getenv("YV3_BIG_MIN") ? atoi(getenv("YV3_BIG_MIN")) : 128;
+        const bool sk_ok = np == 2 && p.ws && use_pp;
+        const int big_min = d->big_tile_min > 0 ? d->big_tile_min : 128;
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
     }

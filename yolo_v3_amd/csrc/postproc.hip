@@ -27,14 +27,22 @@ constexpr int ROW_BITS = 20;                 // rows per image < 2^20
 constexpr u64 ROW_MASK = (1ull << ROW_BITS) - 1;
 constexpr int CLS_SHIFT = 52;                // 32 score bits in [20,52), class above
 
+// Order-preserving map float -> uint32 for ALL finite floats (negative scores pass a negative obj_conf_thr):
+// flip every bit of a negative number, only the sign bit of a non-negative one; ascending uint == ascending float.
+__device__ inline uint32_t ord_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ inline float ord_float(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
 __device__ inline u64 make_key(int cls, float score, int row) {
-    // score > thr > -inf; for non-negative floats the bit pattern is monotonic, so ~bits sorts descending
-    const uint32_t sb = ~__float_as_uint(score);
+    const uint32_t sb = ~ord_bits(score + 0.0f);               // (-0 -> +0: equal scores tie on the row, as torch.sort does); inverted: ascending key == descending score
     return ((u64)cls << CLS_SHIFT) | ((u64)sb << ROW_BITS) | (u64)row;
 }
 __device__ inline int key_cls(u64 k) { return (int)(k >> CLS_SHIFT); }
 __device__ inline int key_row(u64 k) { return (int)(k & ROW_MASK); }
-__device__ inline float key_score(u64 k) { return __uint_as_float(~(uint32_t)(k >> ROW_BITS)); }
+__device__ inline float key_score(u64 k) { return ord_float(~(uint32_t)(k >> ROW_BITS)); }
 
 // torch.max / torch.min propagate NaN; C fmaxf/fminf do not.
 __device__ inline float tmax(float a, float b) { return (a > b || a != a) ? a : b; }

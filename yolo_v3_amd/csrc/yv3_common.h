@@ -17,6 +17,16 @@ typedef unsigned short u16;
 
 static inline int yv3_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Compute units of the CURRENT device, rounded down to a multiple of 8 (equal workgroups per XCD).  Queried per
+// call (the runtime serves it from its cached device properties): no process-global state keyed on "whichever
+// device launched first".
+static inline int yv3_num_cu() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+    return n >= 8 ? n & ~7 : 256;
+}
+
 // float -> bf16 bits, round to nearest even (NaN kept quiet)
 __host__ __device__ static inline u16 yv3_f2bf(float f) {
     union { float f; uint32_t u; } v; v.f = f;

@@ -269,8 +269,36 @@ class YoloNet(nn.Module):
         return eng
 
     def repack(self):
-        """Drop packed weights/plans (they are also refreshed automatically when parameters change)."""
+        """Drop packed weights, plans and cached detectors; the next forward re-packs from the current parameters.
+
+        Packed weights follow the parameters automatically for everything that changes a parameter's
+        ``(data_ptr, _version)``: ``load_state_dict``, ``loadWeight`` / ``WeightManager``, assignments, in-place ops on
+        the parameter.  Writes through ``param.data`` (``p.data.copy_(..)``, the reference loader's idiom,
+        darknet.py:275) are invisible to that check: call ``repack()`` after them, or set
+        ``net.weight_check = "checksum"`` (engine.Engine._signature)."""
         self._engines = {}
+        self.__dict__.pop("_detectors", None)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        self.repack()
+        return out
+
+    # engines / detectors hold ctypes descriptor arrays (raw device pointers): never copied or pickled with the module
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engines"] = {}
+        state.pop("_detectors", None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def forward_cat(self, x, dtype=None):
         """The three scales already concatenated: ``[B, N, 5+C]`` == ``torch.cat((det1,det2,det3), 1)``."""
@@ -299,6 +327,7 @@ class YoloNet(nn.Module):
             self.load_state_dict(torch.load(weights_path, map_location="cpu"))
         elif format == 'darknet':
             WeightManager(self).loadWeight(weights_path)
+        self.repack()
 
 
 class WeightManager:
@@ -310,6 +339,7 @@ class WeightManager:
     """
 
     def __init__(self, model):
+        self.model = model
         self.conv_list = self.find_conv_layers(model)
         self.header = None
         self.seen = None
@@ -375,4 +405,6 @@ class WeightManager:
             else:
                 take(m.bias)
                 take(m.weight)
+        if hasattr(self.model, "repack"):
+            self.model.repack()
         return ptr

@@ -39,11 +39,22 @@ class Detector:
         self.boxes = None
 
     # -- pipeline pieces (all asynchronous on the current stream)
-    def _enqueue(self, x):
-        self.engine.run_convs(self.plan, x, self.dets)
+    def _enqueue(self, x, mark=None):
+        """`mark(name)`, if given, is called at every stage boundary (bench.py records a HIP event on the launch
+        stream there: per-stage split conv0 / convs / decode / filter / nms)."""
+        mark = mark or (lambda name: None)
+        mark("start")
+        self.engine.run_conv0(self.plan, x)
+        mark("conv0")
+        self.engine.run_conv_sequence(self.plan, self.dets)
+        mark("convs")
         self.engine.run_decode(self.plan, self.dets)
+        mark("decode")
         # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
-        self.boxes, _ = self.pp.run_sync_free(self.dets, self.conf, self.nms_thr, self.is_eval, self.use_nms, prob=True)
+        self.pp.filter(self.dets, self.conf, self.is_eval, prob=True)
+        mark("filter")
+        self.boxes = self.pp.nms(self.dets, self.nms_thr, self.use_nms, self.pp.max_cand, self.pp.cap)
+        mark("nms")
 
     def _capture(self, x):
         self._static_in = torch.empty_like(x)
@@ -59,7 +70,7 @@ class Detector:
             self._enqueue(self._static_in)
         self._graph = g
 
-    def run_device(self, imgs):
+    def run_device(self, imgs, mark=None):
         """Enqueue one batch; returns (boxes [B,cap,7], counts [2B]) still on the GPU, no sync."""
         x = self.engine.prepare_input(imgs)
         if tuple(x.shape) != self.shape:
@@ -76,7 +87,7 @@ class Detector:
                 self._static_in.copy_(x)
                 self._graph.replay()
             else:
-                self._enqueue(x)
+                self._enqueue(x, mark)
         return self.boxes, self.pp.counts
 
     def __call__(self, imgs):

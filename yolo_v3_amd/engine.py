@@ -93,16 +93,21 @@ def pack_conv(module, spec, dtype):
         alpha = None
         beta = bias.detach().float().contiguous().clone()
     if dtype == F32H2 and spec.cin != 3:
-        # fp16 planes keep a relative precision of 2^-23 only above 2^-14 * 2^11: bring the weights to O(1)
-        # with an exact power-of-two scale and fold its inverse into the epilogue scale (also exact)
-        wmax = float(w32.abs().max())
-        e = -math.floor(math.log2(wmax)) if wmax > 0 else 0
-        w32 = w32 * (2.0 ** e)
-        alpha = (alpha if alpha is not None else torch.ones(spec.cout, device=dev, dtype=torch.float32)) * (2.0 ** -e)
+        # fp16 planes keep a relative precision of 2^-22 only while the `lo` part is a normal fp16 number, i.e. for
+        # |w| >= 2^-3 after scaling: bring EVERY OUTPUT CHANNEL's weights to max|w_row| in [1,2) with its own exact
+        # power-of-two scale and fold the inverse into that channel's epilogue scale (also exact) -- rows whose
+        # weights are all tiny relative to the layer maximum then keep their relative precision
+        wmax = w32.abs().amax(dim=(1, 2, 3))
+        e = torch.where(wmax > 0, -torch.floor(torch.log2(wmax.clamp(min=1e-38))), torch.zeros_like(wmax))
+        e = e.clamp(-100.0, 100.0)
+        w32 = w32 * torch.exp2(e).view(-1, 1, 1, 1)
+        alpha = (alpha if alpha is not None else torch.ones(spec.cout, device=dev, dtype=torch.float32)) * torch.exp2(-e)
     if spec.cin == 3:
         # first layer: direct-conv kernel wants [cin][kh][kw][cout] fp32
         return PackedConv(spec, w32.permute(1, 2, 3, 0).contiguous(), alpha, beta, spec.cout)
     cout_pad = (spec.cout + 31) // 32 * 32
+    if dtype != F32 and cout_pad > 128:
+        cout_pad = (cout_pad + 127) // 128 * 128     # plane kernels tile the channels by 128 (any class count, e.g. 3*(5+40) = 135 -> 256)
     nw = cout_pad * spec.k * spec.k * spec.cin
     wp = torch.empty(max(1, PLANES[dtype]) * nw, device=dev, dtype=_TORCH_DTYPE[dtype])
     _ffi.check(lib.yv3_pack_conv_weight(w32.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, spec.k,
@@ -110,9 +115,21 @@ def pack_conv(module, spec, dtype):
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
 
+def tuning_options():
+    """Kernel-selection overrides for A/B measurements (tools/): read from the environment HERE, on the host side of
+    the C-ABI, and passed in yv3_conv_desc.options / .big_tile_min -- the library itself reads no environment."""
+    opts = 0
+    if os.environ.get("YV3_NO_PP"):
+        opts |= _ffi.OPT_NO_PINGPONG
+    if os.environ.get("YV3_K3S1"):
+        opts |= _ffi.OPT_K3S1
+    return opts, int(os.environ.get("YV3_BIG_MIN", "0") or 0)
+
+
 def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None):
     sp = pc.spec
     d = ConvDesc()
+    d.options, d.big_tile_min = tuning_options()
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
     d.alpha, d.beta = _ptr(pc.alpha), _ptr(pc.beta)
     d.residual, d.y = _ptr(residual), _ptr(y)
@@ -275,16 +292,32 @@ class Engine:
         self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
 
     # -- weights
-    def _signature(self):
-        sig = []
+    def _param_tensors(self):
+        out = []
         for sp in self.specs:
             w, bn, bias = conv_params(self.net.get_submodule(sp.name))
-            ts = (w,) if bn is None else (w, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            out += [w] if bn is None else [w, bn.weight, bn.bias, bn.running_mean, bn.running_var]
             if bias is not None:
-                ts += (bias,)
-            for t in ts:
-                sig.append((t.data_ptr(), t._version))
-        return tuple(sig)
+                out.append(bias)
+        return out
+
+    def _signature(self):
+        """What the packed weights were built from.  (data_ptr, _version) of every parameter catches assignments,
+        ``load_state_dict``, ``WeightManager`` loads and in-place ops on the parameter itself.  It does NOT see
+        writes through ``param.data`` (``p.data.copy_()`` bumps the version counter of a temporary alias, not of
+        ``p`` -- the reference's own loader idiom, darknet.py:275): after such edits call ``net.repack()``, or set
+        ``net.weight_check = "checksum"`` to add a device-side checksum of all parameters (one fused pass over the
+        248 MB of weights, ~0.1 ms per forward) to the signature."""
+        ts = self._param_tensors()
+        sig = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self.net, "weight_check", "version") == "checksum" and ts and ts[0].is_cuda:
+            with torch.no_grad():
+                norms = torch._foreach_norm([t.detach().float() for t in ts], 1)
+                sums = torch.stack(norms).double()
+                # position-weighted so that swapping two tensors' contents is seen as well
+                chk = float((sums * torch.arange(1, len(ts) + 1, device=sums.device, dtype=torch.float64)).sum())
+            sig += (chk,)
+        return sig
 
     def ensure_packed(self):
         sig = self._signature()
@@ -308,19 +341,26 @@ class Engine:
         return p
 
     # -- execution
-    def run_convs(self, plan, x, dets=None):
-        """conv0 + the 74-descriptor sequence.  With a fused-decode plan `dets` (the detections tensor the head
-        convs write) is required and `run_decode` is a no-op."""
-        lib = _ffi.lib()
+    def run_conv0(self, plan, x):
+        """feature.mlist.0 (reads the caller's NCHW batch)."""
+        p0 = self.packed[0]
+        _ffi.check(_ffi.lib().yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
+                                        plan.conv0_out.data_ptr(), plan.B, plan.H, plan.W, self.dtype, plan.flags.data_ptr(),
+                                        _ffi.stream_ptr()), "yv3_conv0")
+
+    def run_conv_sequence(self, plan, dets=None):
+        """The other 74 convolutions.  With a fused-decode plan `dets` (the detections tensor the head convs write)
+        is required and `run_decode` is a no-op."""
         if plan.fused_decode:
             if dets is None:
-                raise _ffi.Yv3Error("this plan decodes inside the head convs: pass the detections tensor to run_convs")
+                raise _ffi.Yv3Error("this plan decodes inside the head convs: pass the detections tensor")
             plan.bind_detections(dets)
-        s = _ffi.stream_ptr()
-        p0 = self.packed[0]
-        _ffi.check(lib.yv3_conv0(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
-                                 plan.conv0_out.data_ptr(), plan.B, plan.H, plan.W, self.dtype, plan.flags.data_ptr(), s), "yv3_conv0")
-        _ffi.check(lib.yv3_conv2d_sequence(plan.descs, plan.n_desc, s), "yv3_conv2d_sequence")
+        _ffi.check(_ffi.lib().yv3_conv2d_sequence(plan.descs, plan.n_desc, _ffi.stream_ptr()), "yv3_conv2d_sequence")
+
+    def run_convs(self, plan, x, dets=None):
+        """conv0 + the 74-descriptor sequence."""
+        self.run_conv0(plan, x)
+        self.run_conv_sequence(plan, dets)
 
     def run_decode(self, plan, dets):
         if plan.fused_decode:
@@ -351,15 +391,20 @@ class Engine:
             plan.flags_host.zero_()
             plan.flags_event = None
             if flag_value & 2:
-                raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out (set YV3_NO_SK=1 and report)")
+                raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out "
+                                    "(stream-K is opt-in: unset net.stream_k / YV3_SK and report)")
             raise _ffi.Yv3Error(self.OVERFLOW_MSG)
 
     def forward(self, x, dets=None):
         """x: [B,3,H,W] fp32 on the GPU -> detections [B, N, 5+C] (cx,cy,w,h,conf,cls...).
 
-        Stays asynchronous.  In F32H2 mode the saturation flag of a call is copied to pinned host memory behind
-        it and examined (without blocking) at the start of the NEXT call on the same plan; `Detector` / `detect`
-        check it synchronously together with the box counts."""
+        In F32H2 mode the kernels' saturation flag of THIS call is copied to pinned host memory behind the last
+        kernel and checked before returning (one event wait: the call then returns with the work complete, like the
+        reference's forward followed by any use of its result), so no entry point built on it -- ``net(x)``,
+        ``forward_cat``, ``detect(is_eval=True)``, ``predict_and_process`` -- can hand out saturated values.
+        ``net.async_forward = True`` restores the fully asynchronous behaviour (the flag of a call is then examined
+        at the start of the next call on the same plan); `Detector` checks the flag with its single D2H copy of the
+        box counts either way.  The other math modes have fp32's exponent range and never wait."""
         x = self.prepare_input(x)
         with torch.cuda.device(x.device):
             self.ensure_packed()
@@ -375,4 +420,7 @@ class Engine:
                 plan.flags_host.copy_(plan.flags, non_blocking=True)
                 plan.flags_event = torch.cuda.Event()
                 plan.flags_event.record()
+                if not getattr(self.net, "async_forward", False):
+                    plan.flags_event.synchronize()
+                    self.raise_if_overflowed(plan, int(plan.flags_host[0]))
         return dets, plan

@@ -77,6 +77,14 @@ def dense_weight_stream(num_class=80, seed=WEIGHT_SEED):
     return weight_stream(num_class, seed, b_obj=1.0, b_cls=1.0)
 
 
+def eval_weight_stream(num_class=80, seed=WEIGHT_SEED):
+    """"SW-eval": same weights, head biases lowered (objectness -7, classes -3) so that at the reference's
+    evaluation thresholds (conf 0.005 / nms 0.45, is_eval=True: evaluate.py:201-204) an image yields ~1-2 k
+    (row, class) candidates, a few hundred in the busiest class -- the regime of a trained network, instead of the
+    > 5e5 pairs SW-1's zero class biases produce at 0.005."""
+    return weight_stream(num_class, seed, b_obj=-7.0, b_cls=-3.0)
+
+
 def write_darknet_weights(path, stream, seen=0):
     """Write ``stream`` as a darknet file: int32 {major=0, minor=2, revision=0}, int64 seen, floats."""
     with open(path, "wb") as fp:
