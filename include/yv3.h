@@ -230,11 +230,17 @@ int yv3_postproc_nms(const float* dets, int B, int N, int num_class, float nms_t
  * ------------------------------------------------------------------------------------------ */
 
 /* Replaces utils.letterbox_image + the /255, HWC->CHW of utils.load_image (utils.py:44-72):
- * img_hwc uint8 RGB [H,W,3] (device) -> out_chw fp32 [3,out_h,out_w] in [0,1]: bicubic resize (cv2
- * INTER_CUBIC convention, A=-0.75, no antialias) to box = int(size*min(out_w/W,out_h/H)), centred
- * (offset out/2 - box/2, utils.py:34-42) on a 128-grey canvas.  Pass out_chw = batch + b*3*out_h*out_w. */
+ * img_hwc uint8 RGB [H,W,3] (device) -> out_chw fp32 [3,out_h,out_w] in [0,1]: cv2.resize(INTER_CUBIC) -- OpenCV's
+ * fixed-point 8-bit path: A=-0.75 coefficients as 11-bit shorts, int32 horizontal pass, (sum + 2^21) >> 22 vertical
+ * pass, no antialias -- to box = int(size*min(out_w/W,out_h/H)), centred (offset out/2 - box/2, utils.py:34-42) on
+ * a 128-grey canvas.  Pass out_chw = batch + b*3*out_h*out_w. */
 int yv3_letterbox(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
                   void* stream);
+
+/* Replaces load_image(mode='resize') (utils.py:68-71): cv2.resize(img, (out_w,out_h)) with the default INTER_LINEAR
+ * (OpenCV's fixed-point 8-bit path; an exact 2x2 shrink is INTER_AREA, as in cv::resize), /255, HWC -> CHW. */
+int yv3_resize_linear(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
+                      void* stream);
 
 /* Replaces boundingbox.correct_yolo_boxes (boundingbox.py:139-149) = letterbox_reverse (:95-116) or
  * rescale_bbox (:119-137) followed by x1y1x2y2 -> xywh.  boxes [B][cap][ld] with x1,y1,x2,y2 in the

@@ -319,36 +319,107 @@ def letterbox_transforms(inner_dim, outer_dim):
     return bw, bh, (ow // 2) - (bw // 2), (oh // 2) - (bh // 2), ratio
 
 
-def _cubic_weights(t):
-    A = -0.75
-    w0 = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
-    w1 = ((A + 2) * t - (A + 3)) * t * t + 1
-    w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
-    return np.stack((w0, w1, w2, 1 - w0 - w1 - w2), -1)
+# cv2.resize for 8-bit images, restated.  THIRD-PARTY ALGORITHM, ABSENT HERE: the reference calls OpenCV
+# (``cv2.resize(img, (box_w, box_h), interpolation=cv2.INTER_CUBIC)`` utils.py:50 and ``cv2.resize(img, dim)``
+# utils.py:68-69); cv2 is not installed in this image and OpenCV is not vendored by the reference (its README pins
+# no version; any 3.4/4.x ``modules/imgproc/src/resize.cpp`` has the algorithm below).  What is restated is the
+# published fixed-point path of ``cv::resize`` for CV_8U:
+#   * sample position   fx = (float)((dx + 0.5) * scale_x - 0.5), scale_x = 1 / ((double)dst_w / src_w);
+#                       sx = floor(fx); fx -= sx                       (resize.cpp, cv::hal::resize coordinate tables)
+#   * INTER_CUBIC       coefficients ``interpolateCubic`` (A = -0.75, float32 arithmetic in the written order),
+#                       stored as ``saturate_cast<short>(c * 2048)`` (INTER_RESIZE_COEF_BITS = 11, round-half-even);
+#                       horizontal pass ``HResizeCubic<uchar,int,short>``: int32 sums of 4 taps, replicated border;
+#                       vertical pass ``VResizeCubic`` + ``FixedPtCast<int,uchar,22>``:
+#                       ``saturate_cast<uchar>((sum4 + (1 << 21)) >> 22)``
+#   * INTER_LINEAR      (the default of ``cv2.resize(img, dim)``): coefficients (1 - fx, fx) * 2048 as shorts, left /
+#                       right edge clamps (sx < 0 -> sx = 0, fx = 0; sx >= w - 1 -> sx = w - 1, fx = 0); vertical pass
+#                       ``VResizeLinear<uchar,int,short,...>``:
+#                       ``uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2)``;
+#                       an exact 2x2 down-scale is rerouted to INTER_AREA: ``(a + b + c + d + 2) >> 2``.
+# PARITY UNPINNED: without cv2 no golden vector can be produced here.  Known caveat: SIMD builds of OpenCV run the
+# cubic vertical pass of the bulk of each row in float32 (``VResizeCubicVec_32s8u``: v_muladd + v_round), which can
+# differ from this scalar fixed-point definition by 1 LSB on ~1e-4 of the pixels (exact and near ties).
+INTER_RESIZE_COEF_SCALE = 2048
+
+
+def _cv_coords(dst_n, src_n):
+    """(integer source index, float32 fraction) per destination index, as cv::resize tabulates them."""
+    scale = 1.0 / (float(dst_n) / float(src_n))                                   # double
+    f = ((np.arange(dst_n, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    return s, (f - s.astype(np.float32)).astype(np.float32)
+
+
+def _cv_round_short(c):
+    """saturate_cast<short>(float): round half to even, clamp."""
+    return np.clip(np.rint(c.astype(np.float32) * np.float32(INTER_RESIZE_COEF_SCALE)), -32768, 32767).astype(np.int64)
+
+
+def _cv_cubic_coeffs(x):
+    """interpolateCubic (float32, operation order of the source)."""
+    x = x.astype(np.float32)
+    A = np.float32(-0.75)
+    one, x1 = np.float32(1.0), (x + np.float32(1.0)).astype(np.float32)
+    c0 = ((A * x1 - np.float32(5.0) * A) * x1 + np.float32(8.0) * A) * x1 - np.float32(4.0) * A
+    c1 = ((A + np.float32(2.0)) * x - (A + np.float32(3.0))) * x * x + one
+    xm = (one - x).astype(np.float32)
+    c2 = ((A + np.float32(2.0)) * xm - (A + np.float32(3.0))) * xm * xm + one
+    c3 = one - c0 - c1 - c2
+    return np.stack([c.astype(np.float32) for c in (c0, c1, c2, c3)], -1)
+
+
+def cv_resize_cubic_u8(img, dst_w, dst_h):
+    """cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) for uint8 [H,W,C] (fixed-point path)."""
+    H, W = img.shape[:2]
+    sx, fx = _cv_coords(dst_w, W)
+    sy, fy = _cv_coords(dst_h, H)
+    ax, ay = _cv_round_short(_cv_cubic_coeffs(fx)), _cv_round_short(_cv_cubic_coeffs(fy))   # [dst,4] int
+    cols = np.clip(sx[:, None] + np.arange(-1, 3)[None, :], 0, W - 1)                      # replicate border
+    rows = np.clip(sy[:, None] + np.arange(-1, 3)[None, :], 0, H - 1)
+    src = img.astype(np.int64)
+    hor = (src[:, cols, :] * ax[None, :, :, None]).sum(2)                                  # [H,dst_w,C] int32 range
+    val = (hor[rows, :, :] * ay[:, :, None, None]).sum(1)                                  # [dst_h,dst_w,C]
+    return np.clip((val + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+
+
+def cv_resize_linear_u8(img, dst_w, dst_h):
+    """cv2.resize(img, (dst_w, dst_h)) -- the default INTER_LINEAR -- for uint8 [H,W,C] (fixed-point path)."""
+    H, W = img.shape[:2]
+    if W == 2 * dst_w and H == 2 * dst_h:                                                   # rerouted to INTER_AREA (resizeAreaFast)
+        s = img.astype(np.int64)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    sx, fx = _cv_coords(dst_w, W)
+    sy, fy = _cv_coords(dst_h, H)
+    lo, hi = sx < 0, sx >= W - 1
+    fx = np.where(lo | hi, np.float32(0.0), fx).astype(np.float32)
+    sx = np.where(lo, 0, np.where(hi, W - 1, sx))
+    ax = _cv_round_short(np.stack((np.float32(1.0) - fx, fx), -1))
+    ay = _cv_round_short(np.stack((np.float32(1.0) - fy, fy), -1))
+    cols = np.clip(sx[:, None] + np.arange(2)[None, :], 0, W - 1)
+    rows = np.clip(sy[:, None] + np.arange(2)[None, :], 0, H - 1)
+    src = img.astype(np.int64)
+    hor = (src[:, cols, :] * ax[None, :, :, None]).sum(2)
+    r0, r1 = hor[rows[:, 0]], hor[rows[:, 1]]
+    b0, b1 = ay[:, 0, None, None], ay[:, 1, None, None]
+    return (((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2)).astype(np.uint8)
 
 
 def letterbox_image(img, dim):
-    """reference utils.py:44-72 (letterbox_image + the /255, CHW of load_image) with cv2.resize(INTER_CUBIC)
-    restated in float arithmetic (A=-0.75, half-pixel centres, replicate border, no antialias).  cv2 is not
-    available here, so agreement with cv2's fixed-point uint8 path is UNPINNED (may differ by 1 LSB).
-    img: uint8 [H,W,3]; dim = (w,h).  Returns float32 [3,h,w] in [0,1]."""
+    """reference utils.py:44-72 (letterbox_image + the /255, CHW of load_image): cv2.INTER_CUBIC resize to the box
+    (restated above, parity with cv2 UNPINNED), pasted on a 128-grey canvas.  img: uint8 [H,W,3]; dim = (w,h).
+    Returns float32 [3,h,w] in [0,1]."""
     H, W = img.shape[:2]
     ow, oh = dim
     bw, bh, bx, by, _ = letterbox_transforms((W, H), (ow, oh))
-    fx = (np.arange(bw, dtype=np.float32) + np.float32(0.5)) * (np.float32(W) / np.float32(bw)) - np.float32(0.5)
-    fy = (np.arange(bh, dtype=np.float32) + np.float32(0.5)) * (np.float32(H) / np.float32(bh)) - np.float32(0.5)
-    ix, iy = np.floor(fx).astype(np.int64), np.floor(fy).astype(np.int64)
-    wx = _cubic_weights((fx - ix).astype(np.float64))
-    wy = _cubic_weights((fy - iy).astype(np.float64))
-    src = img.astype(np.float64)
-    cols = np.clip(ix[:, None] + np.arange(-1, 3)[None, :], 0, W - 1)          # [bw,4]
-    rows = np.clip(iy[:, None] + np.arange(-1, 3)[None, :], 0, H - 1)          # [bh,4]
-    tmp = (src[:, cols, :] * wx[None, :, :, None]).sum(2)                       # [H,bw,3]
-    box = (tmp[rows, :, :] * wy[:, :, None, None]).sum(1)                       # [bh,bw,3]
-    box = np.clip(np.rint(box), 0, 255)
-    canvas = np.full((oh, ow, 3), 128.0)
-    canvas[by:by + bh, bx:bx + bw] = box
+    canvas = np.full((oh, ow, 3), 128, dtype=np.uint8)
+    canvas[by:by + bh, bx:bx + bw] = cv_resize_cubic_u8(img, bw, bh)
     return torch.from_numpy((canvas.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())
+
+
+def resize_image(img, dim):
+    """reference utils.py:68-71, mode='resize': cv2.resize(img, dim) (INTER_LINEAR), /255, CHW."""
+    out = cv_resize_linear_u8(img, dim[0], dim[1])
+    return torch.from_numpy((out.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())
 
 
 def correct_yolo_boxes(bboxes, org_w, org_h, img_w, img_h, is_letterbox=False):

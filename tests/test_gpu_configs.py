@@ -61,11 +61,13 @@ def test_config2_all_32_images_vs_oracle(net, sw1_sd, mode):
 # ----------------------------------------------------------------------------- configs[2]
 def test_config3_bf16_every_layer_vs_bf16_oracle():
     """YV3_BF16 kernels, layer by layer, each fed the bf16 oracle's activations (608x608, B=2, seed 2).  By the
-    definition in oracle_cpu (``prec="bf16"``) products are exact and only the fp32 summation order differs, so a
-    stored activation can differ from the oracle's by at most ONE bfloat16 rounding step (the fp32 sums differ by
-    ~1e-6 relative; when that straddles a rounding boundary the stored value flips to the neighbouring bf16), and
-    only rarely: expected fraction ~ 2 * 3e-6 / 2^-8 ~ 1e-3.  Asserted: |d| <= 1 bf16 ulp everywhere, flips on
-    < 1 % of the elements of every layer; the fp32 head logits within 2e-5 * max(1,|ref|)."""
+    definition in oracle_cpu (``prec="bf16"``) products are exact and only the fp32 summation order differs: the fp32
+    value before the final rounding differs from the oracle's by fp32 round-off, eps = 5e-6 * max(1,|ref|) at most
+    (the fp32-class modes measure ~1e-6 per layer), so a STORED activation differs by at most that plus ONE bfloat16
+    rounding step (when the two fp32 values straddle a rounding boundary the stored value flips to the neighbouring
+    bf16), and only rarely: expected flip fraction ~ 2 * 1e-6 / 2^-8 ~ 5e-4.  Asserted for every one of the 72
+    bf16-output layers: |d| <= 1 bf16 ulp + eps everywhere, and fewer than 1 % of the elements differ at all; the
+    three fp32 head-logit maps within 2e-5 * max(1,|ref|)."""
     assert torch.cuda.is_available()
     torch.cuda.set_device(0)
     stream = synth.weight_stream()
@@ -77,19 +79,20 @@ def test_config3_bf16_every_layer_vs_bf16_oracle():
         oc.head_logits(sd, x, taps, prec="bf16")
     outs = teacher_forced_layers(net, _ffi.BF16, x, taps)
     assert len(outs) == 75
-    worst_frac, worst_ulp = 0.0, 0.0
+    worst_frac, worst_excess = 0.0, -1.0
     for name, (got, ref) in outs.items():
         if name.endswith("mlist.6"):
             assert_close_rel(got, ref, 2e-5, name + " (fp32 logits)")
             continue
         assert torch.equal(ref, oc.round_bf16(ref)) and torch.equal(got, oc.round_bf16(got)), name
         d = (got.double() - ref.double()).abs()
-        ulps = d / torch.maximum(bf16_ulp(ref), bf16_ulp(got))
+        allowed = torch.maximum(bf16_ulp(ref), bf16_ulp(got)) + 5e-6 * ref.abs().double().clamp(min=1.0)
         frac = float((d > 0).double().mean())
-        worst_frac, worst_ulp = max(worst_frac, frac), max(worst_ulp, float(ulps.max()))
-        assert float(ulps.max()) <= 1.0, "%s: %.3g bf16 ulps" % (name, float(ulps.max()))
+        excess = float((d / allowed).max())
+        worst_frac, worst_excess = max(worst_frac, frac), max(worst_excess, excess)
+        assert excess <= 1.0, "%s: difference %.3g x (1 bf16 ulp + fp32 round-off)" % (name, excess)
         assert frac < 0.01, "%s: %.3g of the elements differ" % (name, frac)
-    print("bf16 layers: worst flip fraction %.3g, worst difference %.3g ulp" % (worst_frac, worst_ulp))
+    print("bf16 layers: worst fraction of differing elements %.3g, worst |d| / (1 ulp + eps) %.3g" % (worst_frac, worst_excess))
 
 
 def test_config3_full_size_vs_bf16_oracle():

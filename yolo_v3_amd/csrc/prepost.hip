@@ -2,58 +2,115 @@
 //   letterbox_kernel      reference utils.py:34-72 (letterbox_transforms / letterbox_image / load_image):
 //                         uint8 HWC RGB -> bicubic resize keeping aspect -> centred on a 128-grey canvas ->
 //                         /255 -> fp32 CHW, written straight into the network's NCHW input batch
+//   resize_linear_kernel  reference utils.py:68-71 (load_image mode='resize': cv2.resize(img, dim), INTER_LINEAR)
 //   correct_boxes_kernel  reference boundingbox.py:95-149 (letterbox_reverse / rescale_bbox /
 //                         correct_yolo_boxes): x1y1x2y2 in network pixels -> clipped xywh in the ORIGINAL image
 #include "yv3_common.h"
 
 namespace {
 
-// cv2.INTER_CUBIC convention (reference utils.py:50): Keys kernel with A = -0.75, sample position
-// fx = (dx + 0.5) * scale - 0.5, replicate border, NO antialiasing when shrinking.  cv2 itself is absent
-// from this environment, so parity with its fixed-point uint8 path is unpinned (results can differ by 1
-// LSB); the CPU oracle restates exactly this float formulation.
-__device__ inline void cubic_w(float t, float w[4]) {
+// cv2.resize for CV_8U, fixed-point path (OpenCV modules/imgproc/src/resize.cpp; cv2 itself is absent from this
+// environment, so parity with it is UNPINNED -- the CPU oracle restates exactly this integer algorithm and the
+// kernels match it bit for bit):
+//   coordinates   fx = (float)((dx + 0.5) * scale - 0.5), scale = 1 / ((double)dst / src); sx = floor(fx); fx -= sx
+//   INTER_CUBIC   interpolateCubic (A = -0.75, float32, source operation order) -> saturate_cast<short>(c * 2048);
+//                 HResizeCubic: int32 sum of 4 taps (replicated border); VResizeCubic + FixedPtCast<int,uchar,22>:
+//                 saturate_cast<uchar>((sum + (1 << 21)) >> 22)
+//   INTER_LINEAR  (1 - fx, fx) * 2048 as shorts, edge clamps; VResizeLinear<uchar,int,short>:
+//                 uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2); exact 2x2 down-scale ->
+//                 INTER_AREA (a + b + c + d + 2) >> 2
+// (this translation unit is compiled with -ffp-contract=off: the float32 coefficient arithmetic must not fuse)
+__device__ inline void cv_coord(int d, double scale, int& s, float& f) {
+    const float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(fx);
+    f = fx - (float)s;
+}
+__device__ inline int cv_short(float c) {                      // saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE)
+    return min(max((int)rintf(c * 2048.f), -32768), 32767);
+}
+__device__ inline void cv_cubic_coeffs(float x, int c[4]) {
     const float A = -0.75f;
-    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
-    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
-    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    float w[4];
+    w[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    w[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
     w[3] = 1.f - w[0] - w[1] - w[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = cv_short(w[k]);
 }
 
 __global__ __launch_bounds__(256) void letterbox_kernel(const unsigned char* __restrict__ img, int H, int W,
                                                        float* __restrict__ out, int OH, int OW,
-                                                       int box_w, int box_h, int box_x, int box_y) {
+                                                       int box_w, int box_h, int box_x, int box_y,
+                                                       double scale_x, double scale_y) {
     const int px = blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= OH * OW) return;
     const int oy = px / OW, ox = px - oy * OW;
-    float rgb[3] = {128.f, 128.f, 128.f};
+    int rgb[3] = {128, 128, 128};
     const int bx = ox - box_x, by = oy - box_y;
     if (bx >= 0 && bx < box_w && by >= 0 && by < box_h) {
-        const float sx = (float)W / (float)box_w, sy = (float)H / (float)box_h;
-        const float fx = ((float)bx + 0.5f) * sx - 0.5f, fy = ((float)by + 0.5f) * sy - 0.5f;
-        const int ix = (int)floorf(fx), iy = (int)floorf(fy);
-        float wx[4], wy[4];
-        cubic_w(fx - (float)ix, wx);
-        cubic_w(fy - (float)iy, wy);
-        float acc[3] = {0.f, 0.f, 0.f};
+        int ix, iy, ax[4], ay[4];
+        float fx, fy;
+        cv_coord(bx, scale_x, ix, fx);
+        cv_coord(by, scale_y, iy, fy);
+        cv_cubic_coeffs(fx, ax);
+        cv_cubic_coeffs(fy, ay);
+        int acc[3] = {0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int yy = min(max(iy - 1 + j, 0), H - 1);
-            float row[3] = {0.f, 0.f, 0.f};
+            int row[3] = {0, 0, 0};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xx = min(max(ix - 1 + i, 0), W - 1);
                 const unsigned char* p = img + ((size_t)yy * W + xx) * 3;
-                row[0] += wx[i] * (float)p[0]; row[1] += wx[i] * (float)p[1]; row[2] += wx[i] * (float)p[2];
+                row[0] += ax[i] * (int)p[0]; row[1] += ax[i] * (int)p[1]; row[2] += ax[i] * (int)p[2];
             }
-            acc[0] += wy[j] * row[0]; acc[1] += wy[j] * row[1]; acc[2] += wy[j] * row[2];
+            acc[0] += ay[j] * row[0]; acc[1] += ay[j] * row[1]; acc[2] += ay[j] * row[2];
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[c] = fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);    // saturate_cast<uchar>
+        for (int c = 0; c < 3; ++c) rgb[c] = min(max((acc[c] + (1 << 21)) >> 22, 0), 255);   // FixedPtCast<int,uchar,22>
     }
     const size_t plane = (size_t)OH * OW;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c * plane + px] = rgb[c] / 255.f;                      // utils.py:71
+    for (int c = 0; c < 3; ++c) out[c * plane + px] = (float)rgb[c] / 255.f;                // utils.py:71
+}
+
+// reference utils.py:68-71, mode='resize': cv2.resize(img, dim) (INTER_LINEAR), /255, HWC -> CHW
+__global__ __launch_bounds__(256) void resize_linear_kernel(const unsigned char* __restrict__ img, int H, int W,
+                                                           float* __restrict__ out, int OH, int OW,
+                                                           double scale_x, double scale_y, int area2) {
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= OH * OW) return;
+    const int oy = px / OW, ox = px - oy * OW;
+    int rgb[3];
+    if (area2) {
+        const unsigned char* p = img + ((size_t)(2 * oy) * W + 2 * ox) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = ((int)p[c] + (int)p[3 + c] + (int)p[(size_t)W * 3 + c] + (int)p[(size_t)W * 3 + 3 + c] + 2) >> 2;
+    } else {
+        int ix, iy;
+        float fx, fy;
+        cv_coord(ox, scale_x, ix, fx);
+        cv_coord(oy, scale_y, iy, fy);
+        if (ix < 0) { fx = 0.f; ix = 0; }
+        if (ix >= W - 1) { fx = 0.f; ix = W - 1; }
+        const int a0 = cv_short(1.f - fx), a1 = cv_short(fx);
+        const int b0 = cv_short(1.f - fy), b1 = cv_short(fy);
+        const int x0 = ix, x1 = min(ix + 1, W - 1);
+        const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+        const unsigned char* r0 = img + (size_t)y0 * W * 3;
+        const unsigned char* r1 = img + (size_t)y1 * W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int s0 = (int)r0[x0 * 3 + c] * a0 + (int)r0[x1 * 3 + c] * a1;
+            const int s1 = (int)r1[x0 * 3 + c] * a0 + (int)r1[x1 * 3 + c] * a1;
+            rgb[c] = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        }
+    }
+    const size_t plane = (size_t)OH * OW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c * plane + px] = (float)(rgb[c] & 255) / 255.f;
 }
 
 // boxes [B][cap][ld] (x1,y1,x2,y2 first), counts [B] (or NULL: every row), org_wh [B][2] = original (w,h)
@@ -102,8 +159,19 @@ extern "C" int yv3_letterbox(const unsigned char* img_hwc, int H, int W, float* 
     const int box_w = (int)(W * ratio), box_h = (int)(H * ratio);
     if (box_w <= 0 || box_h <= 0) return YV3_ESHAPE;
     const int box_x = out_w / 2 - box_w / 2, box_y = out_h / 2 - box_h / 2;
+    const double scale_x = 1.0 / ((double)box_w / W), scale_y = 1.0 / ((double)box_h / H);
     hipLaunchKernelGGL(letterbox_kernel, dim3(yv3_ceil_div((long long)out_h * out_w, 256)), dim3(256), 0, (hipStream_t)stream,
-                       img_hwc, H, W, out_chw, out_h, out_w, box_w, box_h, box_x, box_y);
+                       img_hwc, H, W, out_chw, out_h, out_w, box_w, box_h, box_x, box_y, scale_x, scale_y);
+    YV3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int yv3_resize_linear(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w, void* stream) {
+    if (!img_hwc || !out_chw || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return YV3_EINVAL;
+    const double scale_x = 1.0 / ((double)out_w / W), scale_y = 1.0 / ((double)out_h / H);
+    const int area2 = (W == 2 * out_w && H == 2 * out_h) ? 1 : 0;          // cv::resize reroutes an exact 2x2 shrink to INTER_AREA
+    hipLaunchKernelGGL(resize_linear_kernel, dim3(yv3_ceil_div((long long)out_h * out_w, 256)), dim3(256), 0, (hipStream_t)stream,
+                       img_hwc, H, W, out_chw, out_h, out_w, scale_x, scale_y, area2);
     YV3_CHECK_LAUNCH();
     return 0;
 }
