@@ -220,6 +220,17 @@ def test_predict_idiom_matches_oracle_composition(net):
         assert torch.equal(preds[i][:, 0], sd_boxes[i][:, 6])
         assert torch.equal(preds[i][:, 1:], ref)                    # same fp32 ops on the same boxes -> bitwise
         assert float(preds[i][:, 1].min()) >= 0 and float((preds[i][:, 1] + preds[i][:, 3]).max()) <= im.shape[1] + 1e-3
+    # is_letterbox=False (test.py:28,41): plain cv2.resize to the network size, boxes back through rescale_bbox
+    from yolo_v3_amd import resize_batch
+    preds = predict(net, imgs, (416, 416), obj_conf_thr=0.1, is_letterbox=False)
+    rbatch = resize_batch(imgs, (416, 416))
+    for i, im in enumerate(imgs):
+        assert torch.equal(rbatch[i].cpu(), oc.resize_image(im, (416, 416)))
+    rboxes = detect(net, rbatch, obj_conf_thr=0.1)
+    for i, im in enumerate(imgs):
+        ref = oc.correct_yolo_boxes(rboxes[i][:, :4], im.shape[1], im.shape[0], 416, 416, False)
+        assert preds[i].shape == (len(rboxes[i]), 5) and torch.equal(preds[i][:, 0], rboxes[i][:, 6])
+        assert torch.equal(preds[i][:, 1:], ref)
 
 
 @pytest.mark.parametrize("nc,size,mode", [(20, 320, _ffi.F32X3), (1, 352, _ffi.F32), (20, 320, _ffi.F32), (20, 320, _ffi.F32H2), (1, 352, _ffi.F32H2)])

@@ -403,25 +403,43 @@ def test_correct_yolo_boxes_bit_exact_vs_reference(golden_dir):
 
 
 def test_letterbox_vs_oracle(golden_dir):
-    """utils.py:34-72 on the GPU.  cv2 is absent, so the check is against the oracle's float restatement of
-    cv2.INTER_CUBIC (parity with cv2's fixed-point path: unpinned).  fp32 vs fp64 weights may round a .5 case
-    differently: allow <= 1 LSB on at most 0.5 % of the pixels; geometry (box position, grey padding) exact."""
+    """utils.py:34-72 on the GPU: cv2.resize(INTER_CUBIC) as OpenCV's fixed-point 8-bit path defines it (11-bit
+    short coefficients, int32 horizontal pass, (sum + 2^21) >> 22 vertical pass), restated in oracle_cpu from
+    OpenCV's resize.cpp.  PARITY UNPINNED (cv2 absent: no golden vector can be produced here); the kernel equals the
+    oracle's restatement BIT FOR BIT on up- and down-scales, including clipping overshoot; geometry exact."""
     from yolo_v3_amd import letterbox_batch, letterbox_transforms
     imgs = [(synth.uniform01(31 + i, 9, h * w * 3).reshape(h, w, 3) * 255).astype(np.uint8) for i, (h, w) in
-            enumerate([(452, 602), (300, 200), (100, 640), (416, 416), (37, 53)])]
+            enumerate([(452, 602), (300, 200), (100, 640), (416, 416), (37, 53), (1080, 1920)])]
     # smooth structure so that bicubic overshoot / clipping paths are exercised too
     imgs[0][100:200, 150:400] = 255; imgs[0][250:300, :] = 0
     batch, trans = letterbox_batch(imgs, (416, 416))
-    assert batch.shape == (5, 3, 416, 416) and batch.is_cuda
+    assert batch.shape == (6, 3, 416, 416) and batch.is_cuda
     for i, im in enumerate(imgs):
         ref = oc.letterbox_image(im, (416, 416))
         got = batch[i].cpu()
-        d = ((got - ref).abs() * 255.0).round()
-        assert float(d.max()) <= 1.0, float(d.max())
-        assert float((d > 0).float().mean()) <= 5e-3, float((d > 0).float().mean())
+        assert torch.equal(got, ref), "image %d: %d pixels differ" % (i, int((got != ref).sum()))
         bw, bh, bx, by, ratio = letterbox_transforms((im.shape[1], im.shape[0]), (416, 416))
         assert trans[i].tolist()[:4] == [bw, bh, bx, by]
         pad = torch.ones(416, 416, dtype=torch.bool); pad[by:by + bh, bx:bx + bw] = False
         assert torch.equal(got[:, pad], torch.full_like(got[:, pad], 128.0 / 255.0))
+    b608, _ = letterbox_batch(imgs[:2], (608, 608))
+    for i in range(2):
+        assert torch.equal(b608[i].cpu(), oc.letterbox_image(imgs[i], (608, 608)))
     # 602x452 -> 416x312 at y offset 52 (SURVEY config 1)
     assert trans[0].tolist()[:4] == [416, 312, 0, 52]
+
+
+def test_plain_resize_vs_oracle():
+    """load_image(mode='resize') (utils.py:68-71: cv2.resize(img, dim), INTER_LINEAR) on the GPU, bit for bit against
+    the oracle's restatement of OpenCV's fixed-point bilinear path (PARITY UNPINNED: cv2 absent), incl. the exact-2x
+    shrink that cv::resize reroutes to INTER_AREA and an up-scale."""
+    from yolo_v3_amd import resize_batch, load_image
+    shapes = [(452, 602), (832, 832), (100, 640), (416, 416), (37, 53), (1080, 1920)]
+    imgs = [(synth.uniform01(41 + i, 9, h * w * 3).reshape(h, w, 3) * 255).astype(np.uint8) for i, (h, w) in enumerate(shapes)]
+    batch = resize_batch(imgs, (416, 416))
+    assert batch.shape == (6, 3, 416, 416) and batch.is_cuda
+    for i, im in enumerate(imgs):
+        ref = oc.resize_image(im, (416, 416))
+        assert torch.equal(batch[i].cpu(), ref), "image %d: %d values differ" % (i, int((batch[i].cpu() != ref).sum()))
+    one, tr = load_image(imgs[0], mode="resize", dim=(608, 352))
+    assert tr is None and torch.equal(one.cpu(), oc.resize_image(imgs[0], (608, 352)))

@@ -120,16 +120,17 @@ def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=F
 
 def predict(net, images, dim=(416, 416), num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_letterbox=True):
     """The whole of reference test.py:28-46 (``predict``) for a list of uint8 RGB images of any size:
-    GPU letterbox -> network -> post-processing -> boxes mapped back to each ORIGINAL image.
+    GPU letterbox (or, ``is_letterbox=False``, plain resize) -> network -> post-processing -> boxes mapped back to
+    each ORIGINAL image.
 
     Returns one ``[n_i, 5]`` CPU tensor per image: ``cls, x, y, w, h`` (original-image pixels, clipped), exactly
     the rows ``torch.cat((prediction[..., 6:7], correct_yolo_boxes(...)), -1)`` of the reference; images without
     detections give an empty tensor."""
-    from .utils import letterbox_batch
+    from .utils import letterbox_batch, resize_batch
     from . import boundingbox
-    if not is_letterbox:
-        raise NotImplementedError("predict() prepares its input by letterboxing")
-    batch, _ = letterbox_batch(images, dim)
+    # is_letterbox=False: the images were brought to `dim` by a plain resize (load_image mode='resize', utils.py:68-69)
+    # and the boxes go back through rescale_bbox instead of letterbox_reverse (test.py:41, boundingbox.py:139-149)
+    batch = letterbox_batch(images, dim)[0] if is_letterbox else resize_batch(images, dim)
     res = detect(net, batch, num_classes, obj_conf_thr, nms_thr)
     out = []
     for i, img in enumerate(images):
@@ -138,6 +139,6 @@ def predict(net, images, dim=(416, 416), num_classes=None, obj_conf_thr=0.5, nms
             out.append(torch.zeros((0, 5)))
             continue
         org_h, org_w = int(img.shape[0]), int(img.shape[1])
-        xywh = boundingbox.correct_yolo_boxes(pred[:, 0:4], org_w, org_h, int(dim[0]), int(dim[1]), True)
+        xywh = boundingbox.correct_yolo_boxes(pred[:, 0:4], org_w, org_h, int(dim[0]), int(dim[1]), bool(is_letterbox))
         out.append(torch.cat((pred[:, 6:7], xywh), -1))
     return out

@@ -175,6 +175,30 @@ def letterbox_batch(images, dim, device=None):
     return batch, torch.tensor(trans, dtype=torch.float32)
 
 
+def resize_batch(images, dim, device=None):
+    """List of uint8 RGB images (any sizes) -> ``[B,3,dim_h,dim_w]`` fp32 in [0,1] on the GPU by a plain
+    ``cv2.resize(img, dim)`` (INTER_LINEAR) + /255 + HWC -> CHW: reference utils.load_image(mode='resize')
+    (utils.py:68-71), one HIP kernel per image.  ``dim`` = (w, h)."""
+    if not torch.cuda.is_available():
+        raise _ffi.Yv3Error("no GPU available: this package has no CPU path")
+    dev = torch.device(device if device is not None else "cuda")
+    out_w, out_h = int(dim[0]), int(dim[1])
+    lib = _ffi.lib()
+    batch = torch.empty((len(images), 3, out_h, out_w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        keep = []
+        for b, img in enumerate(images):
+            t = img if isinstance(img, torch.Tensor) else torch.from_numpy(img)
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise _ffi.Yv3Error("images must be uint8 [H,W,3] RGB")
+            t = t.to(dev).contiguous()
+            keep.append(t)
+            _ffi.check(lib.yv3_resize_linear(t.data_ptr(), t.shape[0], t.shape[1], batch.data_ptr() + b * 3 * out_h * out_w * 4,
+                                             out_h, out_w, _ffi.stream_ptr()), "yv3_resize_linear")
+        torch.cuda.current_stream().synchronize()
+    return batch
+
+
 def letterbox_image(img, dim):
     """reference utils.py:44-56 signature: HWC uint8 RGB ``img`` -> (HWC image with values 0..255, transform tensor)."""
     batch, trans = letterbox_batch([img], dim)
@@ -192,7 +216,9 @@ def load_image(img, mode=None, dim=None):
     if mode == 'letterbox' and dim is not None:
         batch, trans = letterbox_batch([img], dim)
         return batch[0], trans[0]
-    if mode is not None:
-        raise NotImplementedError("only mode='letterbox' (or None) is provided")
+    if mode == 'resize' and dim is not None:
+        return resize_batch([img], dim)[0], None
+    if mode is not None and dim is not None:
+        raise ValueError("mode must be 'letterbox' or 'resize'")
     t = img if isinstance(img, torch.Tensor) else torch.from_numpy(img)
     return t.cuda().float().permute(2, 0, 1) / 255, None
