@@ -137,10 +137,13 @@ typedef struct yv3_conv_desc {
     unsigned  options;                /* OR of YV3_OPT_*                                          */
     int       big_tile_min;           /* plane kernels: minimum number of 256x128 tiles for which that tile is
                                          used instead of 128x128 (0: default 128 = half a round of the chip) */
+    int       tune[4];                /* kernel-tuning experiments (0 = off); meaning private to the kernels */
 } yv3_conv_desc;
 
 #define YV3_OPT_NO_PINGPONG 1u    /* fp16-plane 8-wave tiles: single-phase main loop instead of the two-group ping-pong */
 #define YV3_OPT_K3S1        2u    /* 3x3 stride-1 plane convs: the kw-tap-reuse kernel (conv_planes_k3s1.hip)          */
+#define YV3_OPT_TILE_SHIFT  8     /* bits 8..15: force a tile configuration of the fp16-plane kernels (0 = automatic):
+                                     1 = 256x128 / 8 waves, 2 = 128x128 / 8 waves, 3 = 128x128 / 4 waves, two workgroups per CU */
 
 /* Size of yv3_conv_desc.workspace. */
 size_t yv3_conv_workspace_bytes(void);

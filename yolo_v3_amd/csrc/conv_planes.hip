@@ -34,8 +34,10 @@ namespace {
 // fragments of the next chunk from LDS and issues its share of the DMA, then they swap at an s_barrier.
 // Each SIMD's matrix pipe is thereby fed by one wave while its partner wave loads, instead of both
 // waves stalling on LDS / DMA / barrier at the same time.
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvParamsP p) {
+// MINW = 2 (4-wave workgroups only): two workgroups per CU (<= 256 registers per wave); their barriers are independent, so
+// one workgroup's waves feed the matrix pipes while the other's wait for DMA / run their epilogue.
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false, int MINW = 1>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const ConvParamsP p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile: WTM pixels x WTN channels
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -44,10 +46,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     constexpr int STAGE = NP * (A_PLANE + B_PLANE);
     constexpr int AROWS = BM / NW;                        // pixel rows staged per wave (multiple of 16)
     constexpr int AQ = AROWS / RPG;                       // global_load_lds per plane per wave, A side
-    constexpr int BROWS = BN / NW;                        // weight rows staged per wave (<= 16)
-    constexpr int G = NP * (AQ + 1);                      // DMA instructions per chunk per wave
+    constexpr int BROWS = BN / NW;                        // weight rows staged per wave
+    constexpr int BQ = BROWS > RPG ? BROWS / RPG : 1;     // global_load_lds per plane per wave, weight side
+    constexpr int G = NP * (AQ + BQ);                     // DMA instructions per chunk per wave
     constexpr int D = NSTAGE - 1;                         // prefetch distance in chunks
-    static_assert(AROWS % RPG == 0 && BROWS <= RPG && MT >= 1 && NT >= 1, "tile/wave layout");
+    static_assert(AROWS % RPG == 0 && (BROWS <= RPG || BROWS % RPG == 0) && MT >= 1 && NT >= 1, "tile/wave layout");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef YV3_TIMELINE
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     bool aok[AQ];
     const int HoWo = p.Ho * p.Wo;
     // ---- staging, weight side: the packed tile is already in LDS-image (swizzled) order
-    const bool bact = lane < BROWS * SLOTS;
+    const bool bact = lane < (BROWS < RPG ? BROWS : RPG) * SLOTS;
     int m0 = 0, n0 = 0, bin = 0;
     long long btile = 0;
     int kh = 0, kw = 0, c0 = 0;
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
             __builtin_amdgcn_global_load_lds(GPTR(ap[q] + pl * aps[q]),
                                              LPTR(dst + pl * A_PLANE + (AROWS * wid + q * RPG) * ROWB), 16, 0, 0);
         } else if (bact) {
-            const int pl = idx - AQ * NP;
-            __builtin_amdgcn_global_load_lds(GPTR(wbp + (long long)pl * (p.tb * PBK)),
-                                             LPTR(dst + NP * A_PLANE + pl * B_PLANE + wid * (BROWS * ROWB)), 16, 0, 0);
+            const int q = (idx - AQ * NP) / NP, pl = (idx - AQ * NP) % NP;
+            __builtin_amdgcn_global_load_lds(GPTR(wbp + (long long)pl * (p.tb * PBK) + q * (RPG * PBK)),
+                                             LPTR(dst + NP * A_PLANE + pl * B_PLANE + (wid * BROWS + q * RPG) * ROWB), 16, 0, 0);
         }
     };
 
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_planes_kernel(const ConvPar
     epilogue_store<NP, BM, BN, WM, WN, OUT_F32>(acc, p, lds, m0, n0, wid, lane);
 }
 
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE>
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1>
 int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_pp, hipStream_t s) {
     const int mtiles = (p.M + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
@@ -516,7 +519,7 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_
         if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
         if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
     } \
-    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_>), grid, block, lds, s, q); } while (0)
+    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, false, false, MINW>), grid, block, lds, s, q); } while (0)
     if (out_f32) {
         if (k3 || dual) return YV3_ESHAPE;                   // fp32 outputs are the 1x1 head convs
         YV3_LAUNCH(false, false, true);
@@ -625,6 +628,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const u16*)d->residual; p.y = d->y;
     p.H = d->H; p.W = d->W; p.Cin = d->cin; p.Cup = d->cin_up; p.Cout = d->cout;
     p.stride = d->stride; p.act = d->act; p.flags = d->flags;
+    for (int i = 0; i < 4; ++i) p.tune[i] = d->tune[i];
     p.dec_out = nullptr;
     if (d->dec_out) {
         if (d->out_dtype != YV3_F32 || d->cout % 3 || d->dec_stride <= 0.f) return YV3_ESHAPE;
@@ -675,11 +679,21 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // (with the stream-K schedule every CU gets the same share whatever the tile count: one tile per CU suffices)
         const bool sk_ok = np == 2 && p.ws && use_pp;
         const int big_min = d->big_tile_min > 0 ? d->big_tile_min : 128;
+        const int force = (int)((d->options >> YV3_OPT_TILE_SHIFT) & 0xffu);
+        if (np == 2 && force == 3) return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
+        if (force == 1) return YV3_CFG(256, 128, 4, 2, 2);
+        if (force == 2) return YV3_CFG(128, 128, 4, 2, 3);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
     }
-    if (npad % 64 == 0) { p.ntiles = npad / 64; return YV3_CFG(128, 64, 2, 2, 2); }
+    if (npad % 64 == 0) {
+        p.ntiles = npad / 64;
+        // fp16 planes: 2-deep ring (49 KB) -> three workgroups per CU instead of two (+4 % on the 208x208 3x3 layer)
+        if (np == 2) return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s);
+        return YV3_CFG(128, 64, 2, 2, 2);
+    }
     p.ntiles = npad / 32;
+    if (np == 2) return launch_cfg<2, 128, 32, 4, 1, 2>(p, k3, dual, out_f32, false, s);     // (+6 % on the 208x208 1x1 layer)
     return YV3_CFG(128, 32, 4, 1, 2);
 #undef YV3_CFG
 }

@@ -25,6 +25,7 @@ struct ConvParamsP {
     size_t ws_bytes;
     int tb;                     // rows per packed weight tile
     int* flags;                 // optional: bit 0 <- an fp16-plane output was saturated
+    int tune[4];                // tuning experiments (yv3_conv_desc.tune)
 };
 
 // stream-K workspace geometry (yv3_conv_workspace_bytes): one 512-thread workgroup's accumulators per CU + one flag
@@ -87,7 +88,11 @@ template <> struct PlaneOps<2> {
     static __device__ inline float lo(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu)); }
     static __device__ inline float hi(unsigned q) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16)); }
     static __device__ inline f32x16 mfma(bf16x8v a, bf16x8v b, f32x16 c) {
+#ifdef YV3_EXP_BF16MFMA      // power experiment only (wrong numerics): the same bits through the bf16 multiplier array
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+#endif
     }
     static __device__ inline u16 cvt(float v) { return __builtin_bit_cast(unsigned short, sat(v)); }
     static __device__ inline float back(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -166,7 +171,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     constexpr bool PRE = !OUT_F32 && NP <= 2;
     u32x4 rres[PRE ? NPASS : 1][NP];
     if constexpr (PRE) {
-        if (p.res) {
+        if (p.res && !(p.tune[3] & 2)) {
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int m = m0 + wm * WTM + ps * RPP + lane / LPR;
@@ -282,8 +287,10 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
                     qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
                     ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
                 }
-                *reinterpret_cast<u32x4*>(yo) = qh;
-                *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
+                if (!(p.tune[3] & 1)) {                  // (tune[3]: IO ablation for measurements only -- bit 0 no stores, bit 1 no residual loads)
+                    *reinterpret_cast<u32x4*>(yo) = qh;
+                    *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
+                } else { asm volatile("" :: "v"(qh), "v"(ql)); }
             } else {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {

@@ -123,6 +123,7 @@ def tuning_options():
         opts |= _ffi.OPT_NO_PINGPONG
     if os.environ.get("YV3_K3S1"):
         opts |= _ffi.OPT_K3S1
+    opts |= (int(os.environ.get("YV3_TILE", "0") or 0) & 0xff) << 8
     return opts, int(os.environ.get("YV3_BIG_MIN", "0") or 0)
 
 
@@ -130,6 +131,8 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
     sp = pc.spec
     d = ConvDesc()
     d.options, d.big_tile_min = tuning_options()
+    for i, v in enumerate((os.environ.get("YV3_TUNE", "") or "0").split(",")[:4]):
+        d.tune[i] = int(v or 0)
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
     d.alpha, d.beta = _ptr(pc.alpha), _ptr(pc.beta)
     d.residual, d.y = _ptr(residual), _ptr(y)
