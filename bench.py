@@ -13,8 +13,9 @@ GPU (weak scaling, the default), --global-batch fixes the total (strong scaling;
 Rank 0 prints ONE JSON line.
 
 `roofline` is for the dominant kernel family, the implicit-GEMM convolution (conv_planes_kernel<2,...> in the default
-fp16x2-plane mode, 74 launches per step): algorithmic FLOPs (2*MAC) of those 74 convs for the batch divided by the
-duration of their launch sequence, measured with HIP events on the launch stream in every timed step.  In the
+fp16x2-plane mode: 73 launches per step behind the fused two-layer front kernel, 74 in the other modes): algorithmic FLOPs
+(2*MAC) of those convs for the batch divided by the duration of their launch sequence, measured with HIP events on the
+launch stream in every timed step (`all_75_convs_frac`: all 75 convs over front + convs time).  In the
 default mode each fp32 product costs 3 fp16 MFMAs, so the peak for ALGORITHMIC FLOP/s is 2500/3 TFLOP/s and `frac`
 is the utilisation of the 16-bit matrix pipe.  `stages_ms` is the per-stage split from the same events.
 
@@ -155,22 +156,27 @@ class Workload:
         return out
 
     def flops(self):
+        """(2*MAC of all 75 convs, 2*MAC of the launches timed as the 'convs' stage, number of those launches).
+        The 'conv0' stage is the network's front: feature.mlist.0 alone, or -- fp16-plane mode, csrc/conv_front.hip -- the
+        first TWO layers in one launch; the 'convs' stage is the remaining 74 / 73 implicit-GEMM launches."""
         from yolo_v3_amd import arch
         specs = arch.conv_specs()
         hw = arch.conv_output_hw(self.size)
         macs = [h * w * sp.cout * sp.cin * sp.k * sp.k for sp, (h, w) in zip(specs, hw)]
-        return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[1:]) * self.B          # all 75 convs, the 74 implicit-GEMM launches
+        first = 2 if self.det.plan.fused_front else 1
+        return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, len(macs) - first
 
     def summary(self, elapsed, steps):
         st = self.stages_ms()
-        fa, fi = self.flops()
+        fa, fi, nl = self.flops()
         ach = fi / (st["convs"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[self.mode]
         return {"dtype": DTYPE_NAME[self.mode], "value": round(self.B * self.world * steps / elapsed, 2), "unit": "images/sec",
                 "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_img": round(elapsed / steps * 1e3 / (self.B * self.world), 5),
                 "stages_ms": st,
-                "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[self.mode], "achieved": round(ach, 2), "peak": round(peak, 2),
-                             "unit": "TFLOP/s", "frac": round(ach / peak, 4)}}
+                "roofline": {"bound": "mfma", "kernel": "%s (%d launches/step)" % (KERNEL_NAME[self.mode], nl), "achieved": round(ach, 2),
+                             "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches": nl,
+                             "all_75_convs_frac": round(fa / ((st["conv0"] + st["convs"]) * 1e-3) / 1e12 / peak, 4)}}
 
 
 def make_net(stream, size, dev):
@@ -232,9 +238,8 @@ def main():
 
     out = None
     if rank == 0:
-        fa, fi = main_w.flops()
+        fa, fi, n_desc = main_w.flops()
         st = head["stages_ms"]
-        n_desc = main_w.det.plan.n_desc
         out = {
             "metric": "images/sec (YOLOv3 forward + decode + NMS, %dx%d, bs=%d per GPU)" % (args.size, args.size, B),
             "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,8 +252,8 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "entry": "Detector.run_device",
                        "boxes_kept_first_images": kept4},
             "stages_ms": st,
-            "roofline": dict(head["roofline"], kernel="%s (74 launches/step)" % KERNEL_NAME[args.dtype], traffic=None,
-                             conv_ms_per_step=st["convs"], launches=n_desc, avg_launch_ms=round(st["convs"] / n_desc, 5),
+            "roofline": dict(head["roofline"], traffic=None,
+                             conv_ms_per_step=st["convs"], avg_launch_ms=round(st["convs"] / n_desc, 5),
                              flop_per_launch_avg=fi / n_desc,
                              end_to_end_frac=round(fa / (head["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)),
         }

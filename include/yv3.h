@@ -91,6 +91,16 @@ int yv3_merge_planes(const void* in, float* out, long long n, int np, void* stre
 int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
               void* y_nhwc, int B, int H, int W, int out_dtype, int* flags, void* stream);
 
+/* The first TWO layers in one launch (YV3_F32_F16X2 only): feature.mlist.0 = conv_bn_relu(3,32,3) (darknet.py:76) followed
+ * by feature.mlist.1 = conv_bn_relu(32,64,3,s=2) (darknet.py:68-70), the first layer's [B,H,W,32] activation kept on chip.
+ * Bit-identical to yv3_conv0(..., YV3_F32_F16X2) followed by yv3_conv2d on its output.  x_nchw as for yv3_conv0; w0 /
+ * alpha0 / beta0 = the first layer's parameters as for yv3_conv0; w1_packed = the second layer's weights from
+ * yv3_pack_conv_weight(cout 64, cin 32, k 3, cout_pad 64, YV3_F32_F16X2); y = 2 fp16 planes [2][B,H/2,W/2,64].
+ * H and W must be multiples of 32.  flags: as yv3_conv_desc.flags. */
+int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
+                   const void* w1_packed, const float* alpha1, const float* beta1, void* y,
+                   int B, int H, int W, int* flags, void* stream);
+
 typedef struct yv3_conv_desc {
     const void*  x;         /* NHWC [B,H,W,cin] -- or, when cin_up > 0, the LOW-resolution map
                                [B,H/2,W/2,cin_up] that is nearest-x2 upsampled on the fly      */

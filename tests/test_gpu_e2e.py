@@ -106,12 +106,12 @@ def test_conv_trunk_vs_oracle_layerwise(net, sw1_stream, mode):
     with torch.no_grad():
         oc.head_logits(sd, x, taps)
         eng = net.engine(mode)
-        eng.fuse_decode, eng._plans = False, {}               # materialise the head convs' logits for this check
+        eng.fuse_decode, eng.fuse_front, eng._plans = False, False, {}     # materialise the head logits and the first layer's output
         try:
             _, plan = eng.forward(x.cuda())
             torch.cuda.synchronize()
         finally:
-            eng.fuse_decode, eng._plans = True, {}
+            eng.fuse_decode, eng.fuse_front, eng._plans = True, True, {}
     assert len(taps) == 75
     worst = 0.0
     for name, ref in taps:

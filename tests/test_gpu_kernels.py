@@ -443,3 +443,33 @@ def test_plain_resize_vs_oracle():
         assert torch.equal(batch[i].cpu(), ref), "image %d: %d values differ" % (i, int((batch[i].cpu() != ref).sum()))
     one, tr = load_image(imgs[0], mode="resize", dim=(608, 352))
     assert tr is None and torch.equal(one.cpu(), oc.resize_image(imgs[0], (608, 352)))
+
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 416, 416), (1, 608, 608), (3, 320, 480), (2, 96, 64), (5, 32, 32)])
+def test_fused_front_equals_two_launches_bitwise(B, H, W):
+    """csrc/conv_front.hip (feature.mlist.0 + feature.mlist.1 in one launch, the first layer's activation kept in LDS) writes
+    BIT FOR BIT what yv3_conv0 followed by yv3_conv2d writes (same products, same order), on square / non-square / tiny
+    inputs incl. all four image borders; whole-net detections are therefore identical too; saturation is still reported."""
+    from yolo_v3_amd import YoloNet, WeightManager
+    stream = synth.weight_stream()
+    net = YoloNet((W, H)).eval()
+    assert WeightManager(net).load_stream(stream) == stream.size
+    net = net.cuda()
+    x = torch.from_numpy(synth.images(B, max(H, W), 7)[:, :, :H, :W].copy()).cuda()
+    eng = net.engine(_ffi.F32H2)
+    outs, dets = [], []
+    for fused in (False, True):
+        eng.fuse_front, eng._plans = fused, {}
+        try:
+            d, plan = eng.forward(x)
+            assert plan.fused_front == fused
+            outs.append(plan.layer_out["feature.mlist.1"].clone())
+            dets.append(d.clone())
+        finally:
+            eng.fuse_front, eng._plans = True, {}
+    assert outs[0].shape == (2, B, H // 2, W // 2, 64)
+    assert torch.equal(outs[0], outs[1]), "%d elements differ" % int((outs[0] != outs[1]).sum())
+    assert torch.equal(dets[0], dets[1])
+    with pytest.raises(_ffi.Yv3Error, match="fp16 range"):
+        net.forward_cat(x * 1e4)                               # |x| * 16 leaves the fp16 range of the first layer's operands

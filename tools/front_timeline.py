@@ -1,0 +1,19 @@
+"""Cycle split of the fused front kernel (debug build with -DYV3_FRONT_TL; YV3_LIB points at it)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_v3_amd import YoloNet, WeightManager, synth, _ffi
+torch.cuda.set_device(0)
+net = YoloNet((416, 416)).eval(); WeightManager(net).load_stream(synth.weight_stream()); net = net.cuda()
+eng = net.engine(); eng.ensure_packed()
+plan = eng.plan(64, 416, 416)
+x = torch.rand(64, 3, 416, 416, device="cuda")
+for _ in range(3):
+    eng.run_front(plan, x)
+torch.cuda.synchronize()
+y = plan.layer_out["feature.mlist.1"]
+d = y.view(-1)[:8 * 8 * 2].view(torch.float32).cpu().view(8, 8)
+names = ["patch->LDS", "barrier waits", "first layer", "second conv", "epilogue"]
+for w in range(8):
+    n = float(d[w, 5])
+    print("wave %d: tiles %d | " % (w, n) + "  ".join("%s %.0f" % (nm, float(d[w, i]) / n) for i, nm in enumerate(names)) + "  | total/tile %.0f" % (float(d[w, :5].sum()) / n))

@@ -18,6 +18,6 @@ pmc)   for c in MFMA FETCH WRITE; do
          timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o t -- python bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/${TAG}_pmc_$c.err
        done
        python tools/mfma_util_summary.py $O/${TAG}_pmc_MFMA > $O/${TAG}_mfma_util.json; cat $O/${TAG}_mfma_util.json | head -60
-       python tools/traffic_summary.py $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE 4 74 > $O/${TAG}_traffic_f32h2_416_bs64.json; cat $O/${TAG}_traffic_f32h2_416_bs64.json
+       python tools/traffic_summary.py $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE 4 73 > $O/${TAG}_traffic_f32h2_416_bs64.json; cat $O/${TAG}_traffic_f32h2_416_bs64.json
        rm -rf $O/${TAG}_pmc_MFMA $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE ;;
 esac; done

@@ -24,6 +24,9 @@ for (cin, cout, k, s, H, tile), n, ms in rows:
     hin = H * s
     res = (k == 3 and s == 1 and cin * 2 == cout and cin >= 32 and tile != "conv0")        # res_layer.conv2 (also the branch 3x3s: see note)
     in_bytes = B * hin * hin * cin * (4 if cin != 3 else 4)
+    if str(tile).startswith("conv_front"):                             # fused front: reads the 3-channel image, FLOPs of both layers
+        in_bytes = B * hin * hin * 3 * 4
+        flops += 2.0 * B * hin * hin * 32 * 27
     out_bytes = M * cout * 4
     w_bytes = cout * cin * k * k * 4
     byts = in_bytes + out_bytes + w_bytes + (out_bytes if res else 0)

@@ -44,7 +44,7 @@ class Detector:
         stream there: per-stage split conv0 / convs / decode / filter / nms)."""
         mark = mark or (lambda name: None)
         mark("start")
-        self.engine.run_conv0(self.plan, x)
+        self.engine.run_front(self.plan, x)
         mark("conv0")
         self.engine.run_conv_sequence(self.plan, self.dets)
         mark("convs")

@@ -30,7 +30,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # YV3_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (RCCL wants one GPU per rank)
+            backend = os.environ.get("YV3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

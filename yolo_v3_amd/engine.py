@@ -184,6 +184,9 @@ class Plan:
         # materialised and the descriptors' dec_out is pointed at the caller's detections tensor before each launch
         self.fused_decode = bool(engine.fuse_decode and dt != F32)
         self.head_descs = []     # (descriptor index, ho, wo)
+        # fp16-plane mode: feature.mlist.0 + feature.mlist.1 run as ONE launch (csrc/conv_front.hip); the first layer's
+        # [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
+        self.fused_front = bool(engine.fuse_front and dt == F32H2)
 
         def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
             pc = packed[i]
@@ -293,6 +296,7 @@ class Engine:
         # workgroups is summed in a batch-position-dependent order (include/yv3.h, yv3_conv_desc.workspace)
         self.stream_k = bool(getattr(net, "stream_k", os.environ.get("YV3_SK") == "1"))
         self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
+        self.fuse_front = bool(getattr(net, "fuse_front", os.environ.get("YV3_NO_FUSED_FRONT") is None))
 
     # -- weights
     def _param_tensors(self):
@@ -351,18 +355,30 @@ class Engine:
                                         plan.conv0_out.data_ptr(), plan.B, plan.H, plan.W, self.dtype, plan.flags.data_ptr(),
                                         _ffi.stream_ptr()), "yv3_conv0")
 
+    def run_front(self, plan, x):
+        """The network's front: feature.mlist.0 alone, or (fused-front plans) feature.mlist.0 + feature.mlist.1 in one launch
+        whose output is descriptor 0's output buffer."""
+        if not plan.fused_front:
+            return self.run_conv0(plan, x)
+        p0, p1, d1 = self.packed[0], self.packed[1], plan.descs[0]
+        _ffi.check(_ffi.lib().yv3_conv_front(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
+                                             p1.w.data_ptr(), p1.alpha.data_ptr(), p1.beta.data_ptr(), d1.y,
+                                             plan.B, plan.H, plan.W, plan.flags.data_ptr(), _ffi.stream_ptr()), "yv3_conv_front")
+
     def run_conv_sequence(self, plan, dets=None):
-        """The other 74 convolutions.  With a fused-decode plan `dets` (the detections tensor the head convs write)
-        is required and `run_decode` is a no-op."""
+        """The remaining convolutions (74, or 73 behind a fused front).  With a fused-decode plan `dets` (the detections
+        tensor the head convs write) is required and `run_decode` is a no-op."""
         if plan.fused_decode:
             if dets is None:
                 raise _ffi.Yv3Error("this plan decodes inside the head convs: pass the detections tensor")
             plan.bind_detections(dets)
-        _ffi.check(_ffi.lib().yv3_conv2d_sequence(plan.descs, plan.n_desc, _ffi.stream_ptr()), "yv3_conv2d_sequence")
+        first = 1 if plan.fused_front else 0
+        tail = ctypes.cast(ctypes.addressof(plan.descs) + first * ctypes.sizeof(ConvDesc), ctypes.POINTER(ConvDesc))
+        _ffi.check(_ffi.lib().yv3_conv2d_sequence(tail, plan.n_desc - first, _ffi.stream_ptr()), "yv3_conv2d_sequence")
 
     def run_convs(self, plan, x, dets=None):
-        """conv0 + the 74-descriptor sequence."""
-        self.run_conv0(plan, x)
+        """All 75 convolutions."""
+        self.run_front(plan, x)
         self.run_conv_sequence(plan, dets)
 
     def run_decode(self, plan, dets):
