@@ -163,7 +163,7 @@ class Workload:
         specs = arch.conv_specs()
         hw = arch.conv_output_hw(self.size)
         macs = [h * w * sp.cout * sp.cin * sp.k * sp.k for sp, (h, w) in zip(specs, hw)]
-        first = 2 if self.det.plan.fused_front else 1
+        first = 1 + self.det.plan.first_desc
         return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, len(macs) - first
 
     def summary(self, elapsed, steps):

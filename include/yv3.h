@@ -101,6 +101,15 @@ int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, const float* 
                    const void* w1_packed, const float* alpha1, const float* beta1, void* y,
                    int B, int H, int W, int* flags, void* stream);
 
+/* The first residual block in one launch (YV3_F32_F16X2 only): feature.mlist.2 = res_layer(64) (darknet.py:46-53),
+ * y = x + conv_bn_relu(32,64,3)(conv_bn_relu(64,32,1)(x)), the 32-channel intermediate kept on chip.  Bit-identical to the two
+ * yv3_conv2d launches.  x, y: 2 fp16 planes [2][B,H,W,64] (H, W = the block's resolution, multiples of 16);
+ * w1_packed / w2_packed from yv3_pack_conv_weight (cout_pad 32 / 64, YV3_F32_F16X2); alpha / beta from yv3_fold_bn (with the
+ * weight scaling folded in, as for yv3_conv2d).  flags: as yv3_conv_desc.flags. */
+int yv3_res_block64(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
+                    const void* w2_packed, const float* alpha2, const float* beta2, void* y,
+                    int B, int H, int W, int* flags, void* stream);
+
 typedef struct yv3_conv_desc {
     const void*  x;         /* NHWC [B,H,W,cin] -- or, when cin_up > 0, the LOW-resolution map
                                [B,H/2,W/2,cin_up] that is nearest-x2 upsampled on the fly      */

@@ -106,7 +106,7 @@ def test_conv_trunk_vs_oracle_layerwise(net, sw1_stream, mode):
     with torch.no_grad():
         oc.head_logits(sd, x, taps)
         eng = net.engine(mode)
-        eng.fuse_decode, eng.fuse_front, eng._plans = False, False, {}     # materialise the head logits and the first layer's output
+        eng.fuse_decode, eng.fuse_front, eng._plans = False, False, {}     # materialise the head logits and the first layers' outputs
         try:
             _, plan = eng.forward(x.cuda())
             torch.cuda.synchronize()

@@ -1,2 +1,2 @@
-export DT=f32h2 ITERS=20 CHECK=0
-for k in 0,0,0 0,0,1 0,0,0 0,0,1; do echo "== TUNE=$k (tune[2]=1: no residual touch)"; YV3_TUNE=$k python tools/conv_bench.py c52 c26 c13 c104; done
+export DT=f32h2 ITERS=30 CHECK=0
+for t in 0 4 3 0 4; do echo "== YV3_TILE=$t"; YV3_TILE=$t python tools/conv_bench.py p52 p26 p13 c104 p104; done

@@ -681,6 +681,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int big_min = d->big_tile_min > 0 ? d->big_tile_min : 128;
         const int force = (int)((d->options >> YV3_OPT_TILE_SHIFT) & 0xffu);
         if (np == 2 && force == 3) return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
+        if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         if (force == 1) return YV3_CFG(256, 128, 4, 2, 2);
         if (force == 2) return YV3_CFG(128, 128, 4, 2, 3);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);

@@ -187,6 +187,9 @@ class Plan:
         # fp16-plane mode: feature.mlist.0 + feature.mlist.1 run as ONE launch (csrc/conv_front.hip); the first layer's
         # [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
         self.fused_front = bool(engine.fuse_front and dt == F32H2)
+        # ... and the first residual block (feature.mlist.2: 1x1 64->32 + 3x3 32->64 + add) as one more (csrc/conv_res64.hip)
+        self.fused_res64 = bool(self.fused_front and engine.fuse_res64)
+        self.first_desc = 3 if self.fused_res64 else (1 if self.fused_front else 0)
 
         def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
             pc = packed[i]
@@ -297,6 +300,7 @@ class Engine:
         self.stream_k = bool(getattr(net, "stream_k", os.environ.get("YV3_SK") == "1"))
         self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
         self.fuse_front = bool(getattr(net, "fuse_front", os.environ.get("YV3_NO_FUSED_FRONT") is None))
+        self.fuse_res64 = bool(getattr(net, "fuse_res64", os.environ.get("YV3_NO_FUSED_RES64") is None))
 
     # -- weights
     def _param_tensors(self):
@@ -357,13 +361,20 @@ class Engine:
 
     def run_front(self, plan, x):
         """The network's front: feature.mlist.0 alone, or (fused-front plans) feature.mlist.0 + feature.mlist.1 in one launch
-        whose output is descriptor 0's output buffer."""
+        whose output is descriptor 0's output buffer -- followed, in fused-res64 plans, by the first residual block
+        (descriptors 1 and 2) as one launch."""
         if not plan.fused_front:
             return self.run_conv0(plan, x)
         p0, p1, d1 = self.packed[0], self.packed[1], plan.descs[0]
         _ffi.check(_ffi.lib().yv3_conv_front(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
                                              p1.w.data_ptr(), p1.alpha.data_ptr(), p1.beta.data_ptr(), d1.y,
                                              plan.B, plan.H, plan.W, plan.flags.data_ptr(), _ffi.stream_ptr()), "yv3_conv_front")
+        if plan.fused_res64:
+            p2, p3, d3 = self.packed[2], self.packed[3], plan.descs[2]
+            _ffi.check(_ffi.lib().yv3_res_block64(d1.y, p2.w.data_ptr(), p2.alpha.data_ptr(), p2.beta.data_ptr(),
+                                                  p3.w.data_ptr(), p3.alpha.data_ptr(), p3.beta.data_ptr(), d3.y,
+                                                  plan.B, plan.H // 2, plan.W // 2, plan.flags.data_ptr(), _ffi.stream_ptr()),
+                       "yv3_res_block64")
 
     def run_conv_sequence(self, plan, dets=None):
         """The remaining convolutions (74, or 73 behind a fused front).  With a fused-decode plan `dets` (the detections
@@ -372,7 +383,7 @@ class Engine:
             if dets is None:
                 raise _ffi.Yv3Error("this plan decodes inside the head convs: pass the detections tensor")
             plan.bind_detections(dets)
-        first = 1 if plan.fused_front else 0
+        first = plan.first_desc
         tail = ctypes.cast(ctypes.addressof(plan.descs) + first * ctypes.sizeof(ConvDesc), ctypes.POINTER(ConvDesc))
         _ffi.check(_ffi.lib().yv3_conv2d_sequence(tail, plan.n_desc - first, _ffi.stream_ptr()), "yv3_conv2d_sequence")
 
