@@ -127,8 +127,10 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int r0 = RT_R * ty, c0 = RT_C * tx;
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my share of this tile's x region (and, first tile, of the weights) has landed
-        __syncthreads();                                          // ... everybody's has; every wave is past the previous epilogue
+        // (this tile's x region -- and, first tile, the weights -- were waited for before the previous epilogue's stores
+        // were issued, see step 4: the stores themselves drain in the background)
+        if (tile == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // everybody's share has landed; every wave is past the previous epilogue
 
         // ---- 2. 1x1 conv (64 -> 32) for the region pixels -> image
         if (wid < 6) {
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
                 acc2 = mfma_unit<2>(wf, xf, acc2);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // residual rows + my share of the NEXT tile's x region (long landed)
         __syncthreads();                                          // the image is dead: its LDS (+ slack) becomes the transpose tiles
 
         // ---- 4. epilogue: BN + LeakyReLU -> per-wave LDS transpose -> + residual -> hi/lo planes
