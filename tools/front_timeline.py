@@ -17,3 +17,13 @@ names = ["patch->LDS", "barrier waits", "first layer", "second conv", "epilogue"
 for w in range(8):
     n = float(d[w, 5])
     print("wave %d: tiles %d | " % (w, n) + "  ".join("%s %.0f" % (nm, float(d[w, i]) / n) for i, nm in enumerate(names)) + "  | total/tile %.0f" % (float(d[w, :5].sum()) / n))
+
+# ---- conv_res64 (debug build with -DYV3_RES_TL)
+if os.environ.get("RES_TL"):
+    eng.run_front(plan, x); torch.cuda.synchronize()
+    y = plan.layer_out["feature.mlist.2.conv2"]
+    d = y.view(-1)[:8 * 8 * 2].view(torch.float32).cpu().view(8, 8)
+    names = ["loop top", "barrier waits", "1x1 -> image", "3x3 conv", "epilogue", "vmcnt wait"]
+    for w in range(8):
+        n = float(d[w, 6])
+        print("res64 wave %d: tiles %d | " % (w, n) + "  ".join("%s %.0f" % (nm, float(d[w, i]) / n) for i, nm in enumerate(names)) + "  | total/tile %.0f" % (float(d[w, :6].sum()) / n))

@@ -20,6 +20,7 @@
 // bit-identical to the two-launch path (tests/test_gpu_kernels.py::test_fused_front_equals_two_launches_bitwise).
 // HBM traffic: 12 B in + 256 B out per second-layer pixel (0.84 GB per step instead of 3.7 GB).
 // LDS: 78 336 (image, re-used by the epilogue transposes) + 73 728 (weights) + 8 208 (patch) = 160 272 B: one workgroup per CU.
+#include <type_traits>
 #include "conv_planes_common.h"
 
 namespace {
@@ -202,54 +203,75 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
         FTL(1);
         if (tile + (int)gridDim.x < p.total) patch_fetch(tile + gridDim.x);       // lands during steps 2-4
 
-        // ---- 2. first layer for the 561 region pixels, 32 per MFMA column block
+        // ---- 2. first layer for the 561 region pixels, 32 per MFMA column block.  A wave's first two groups are processed
+        // TOGETHER (two independent MFMA chains / LDS round trips interleave instead of one dependent chain at a time)
+        auto first_layer = [&](auto ntag, int i0) {
+            constexpr int NG = decltype(ntag)::value;
+            unsigned q0[NG][8], q1[NG][8];
 #pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            if (wid + 8 * i >= FR_GROUPS) break;                                  // wave-uniform
-            const unsigned* p0 = patch + gbase[i] + lhi * FP_CH;
-            unsigned q0[8], q1[8];
+            for (int n = 0; n < NG; ++n) {
+                const unsigned* p0 = patch + gbase[i0 + n] + lhi * FP_CH;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { q0[j] = p0[(j / 3) * FP_PITCH + j % 3]; q1[j] = patch[gbase[i] + d1[j]]; }
-            u32x4 xh[2], xl[2];                                                   // 8 fp16 each: hi / lo parts of the k-step's 8 taps
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                xh[0][q] = __builtin_amdgcn_perm(q0[2 * q + 1], q0[2 * q], 0x05040100u);
-                xl[0][q] = __builtin_amdgcn_perm(q0[2 * q + 1], q0[2 * q], 0x07060302u);
-                xh[1][q] = __builtin_amdgcn_perm(q1[2 * q + 1], q1[2 * q], 0x05040100u);
-                xl[1][q] = __builtin_amdgcn_perm(q1[2 * q + 1], q1[2 * q], 0x07060302u);
+                for (int j = 0; j < 8; ++j) { q0[n][j] = p0[(j / 3) * FP_PITCH + j % 3]; q1[n][j] = patch[gbase[i0 + n] + d1[j]]; }
             }
-            f32x16 acc;
+            f32x16 acc[NG];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int n = 0; n < NG; ++n)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const fh16x8 xhi = __builtin_bit_cast(fh16x8, xh[ks]), xlo = __builtin_bit_cast(fh16x8, xl[ks]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[ks], xhi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ks], xlo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ks], xhi, acc, 0, 0, 0);
-            }
-            const int gy = 2 * r0 - 1 + grow[i], gx = 2 * c0 - 1 + gcol[i];
-            const bool inimg = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            u32x4 qh[2], ql[2];
+                for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+            u32x4 xh[NG][2], xl[NG][2];                                           // 8 fp16 each: hi / lo parts of a k-step's 8 taps
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float t0 = fmaf(acc[2 * q], al0[2 * q], be0[2 * q]), t1 = fmaf(acc[2 * q + 1], al0[2 * q + 1], be0[2 * q + 1]);
-                t0 = __builtin_fmaxf(t0, 0.1f * t0); t1 = __builtin_fmaxf(t1, 0.1f * t1);          // LeakyReLU(0.1)
-                const ff32x2 a = {t0, t1};
-                const fh16x2 h = __builtin_convertvector(a, fh16x2);
-                const fh16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, ff32x2), fh16x2);
-                qh[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, h) : 0u;      // outside the image: the second conv's zero padding
-                ql[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, l) : 0u;
+            for (int n = 0; n < NG; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xh[n][0][q] = __builtin_amdgcn_perm(q0[n][2 * q + 1], q0[n][2 * q], 0x05040100u);
+                    xl[n][0][q] = __builtin_amdgcn_perm(q0[n][2 * q + 1], q0[n][2 * q], 0x07060302u);
+                    xh[n][1][q] = __builtin_amdgcn_perm(q1[n][2 * q + 1], q1[n][2 * q], 0x05040100u);
+                    xl[n][1][q] = __builtin_amdgcn_perm(q1[n][2 * q + 1], q1[n][2 * q], 0x07060302u);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)                                       // per accumulator: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi (conv0.hip's order)
+#pragma unroll
+                    for (int n = 0; n < NG; ++n) {
+                        const fh16x8 xhi = __builtin_bit_cast(fh16x8, xh[n][ks]), xlo = __builtin_bit_cast(fh16x8, xl[n][ks]);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 0 ? wlo[ks] : whi[ks], t == 1 ? xlo : xhi, acc[n], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                const int i = i0 + n;
+                const int gy = 2 * r0 - 1 + grow[i], gx = 2 * c0 - 1 + gcol[i];
+                const bool inimg = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                u32x4 qh[2], ql[2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float t0 = fmaf(acc[n][2 * q], al0[2 * q], be0[2 * q]), t1 = fmaf(acc[n][2 * q + 1], al0[2 * q + 1], be0[2 * q + 1]);
+                    t0 = __builtin_fmaxf(t0, 0.1f * t0); t1 = __builtin_fmaxf(t1, 0.1f * t1);      // LeakyReLU(0.1)
+                    const ff32x2 a = {t0, t1};
+                    const fh16x2 h = __builtin_convertvector(a, fh16x2);
+                    const fh16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, ff32x2), fh16x2);
+                    qh[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, h) : 0u;  // outside the image: the second conv's zero padding
+                    ql[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, l) : 0u;
+                }
+                if (gimg[i] >= 0) {
+                    const int sw = gimg[i] >> 20;
+                    unsigned char* d = lds + (gimg[i] & 0xfffff);
+                    *reinterpret_cast<u32x4*>(d + ((lhi ^ sw) * 16)) = qh[0];                   // channels 8*lhi .. +7
+                    *reinterpret_cast<u32x4*>(d + (((2 + lhi) ^ sw) * 16)) = qh[1];             // channels 16 + 8*lhi .. +7
+                    *reinterpret_cast<u32x4*>(d + FA_PLANE + ((lhi ^ sw) * 16)) = ql[0];
+                    *reinterpret_cast<u32x4*>(d + FA_PLANE + (((2 + lhi) ^ sw) * 16)) = ql[1];
+                }
             }
-            if (gimg[i] >= 0) {
-                const int sw = gimg[i] >> 20;
-                unsigned char* d = lds + (gimg[i] & 0xfffff);
-                *reinterpret_cast<u32x4*>(d + ((lhi ^ sw) * 16)) = qh[0];                       // channels 8*lhi .. +7
-                *reinterpret_cast<u32x4*>(d + (((2 + lhi) ^ sw) * 16)) = qh[1];                 // channels 16 + 8*lhi .. +7
-                *reinterpret_cast<u32x4*>(d + FA_PLANE + ((lhi ^ sw) * 16)) = ql[0];
-                *reinterpret_cast<u32x4*>(d + FA_PLANE + (((2 + lhi) ^ sw) * 16)) = ql[1];
-            }
-        }
+        };
+#if !defined(YV3_FRONT_NG) || YV3_FRONT_NG == 2
+        first_layer(std::integral_constant<int, 2>{}, 0);                          // groups wid, wid + 8 (both < 18 for every wave)
+        if (wid + 16 < FR_GROUPS) first_layer(std::integral_constant<int, 1>{}, 2);   // waves 0, 1: group wid + 16
+#else
+        first_layer(std::integral_constant<int, 1>{}, 0);
+        first_layer(std::integral_constant<int, 1>{}, 1);
+        if (wid + 16 < FR_GROUPS) first_layer(std::integral_constant<int, 1>{}, 2);
+#endif
         // (first tile: every wave has consumed its patch registers, loaded AFTER its share of the weight DMA was issued,
         // so that DMA has landed -- vector-memory loads complete in order)
         FTL(2);

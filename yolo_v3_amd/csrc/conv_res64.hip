@@ -121,6 +121,12 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
 
     if ((int)blockIdx.x < p.total) x_dma(blockIdx.x);
     float amax = 0.f;
+#ifdef YV3_RES_TL        // debug build only (tools/front_timeline.py): cycle split of one workgroup, written over y[0..]
+    unsigned long long tl_t = __builtin_amdgcn_s_memtime(), tl_acc[6] = {0, 0, 0, 0, 0, 0};
+#define RTL(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_acc[i] += t_ - tl_t; tl_t = t_; } while (0)
+#else
+#define RTL(i) do {} while (0)
+#endif
     for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
         const int b = tile / (p.tiles_x * p.tiles_y);
         const int rem = tile - b * (p.tiles_x * p.tiles_y);
@@ -130,7 +136,9 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
         // (this tile's x region -- and, first tile, the weights -- were waited for before the previous epilogue's stores
         // were issued, see step 4: the stores themselves drain in the background)
         if (tile == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RTL(0);
         __syncthreads();                                          // everybody's share has landed; every wave is past the previous epilogue
+        RTL(1);
 
         // ---- 2. 1x1 conv (64 -> 32) for the region pixels -> image
         if (wid < 6) {
@@ -171,7 +179,9 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
                 }
             }
         }
+        RTL(2);
         __syncthreads();                                          // image complete; the x region is free again
+        RTL(1);
         if (tile + (int)gridDim.x < p.total) x_dma(tile + gridDim.x);          // lands during steps 3-4
 
         // residual rows of this wave's 32 x 32 output tile (L2-warm: the region DMA just read them), requested before the 3x3
@@ -203,8 +213,11 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
                 acc2 = mfma_unit<2>(wf, xf, acc2);
             }
         }
+        RTL(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // residual rows + my share of the NEXT tile's x region (long landed)
+        RTL(5);
         __syncthreads();                                          // the image is dead: its LDS (+ slack) becomes the transpose tiles
+        RTL(1);
 
         // ---- 4. epilogue: BN + LeakyReLU -> per-wave LDS transpose -> + residual -> hi/lo planes
         float* tl = reinterpret_cast<float*>(lds + R_I_OFF) + wid * (32 * R_EP);
@@ -244,7 +257,15 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
             *reinterpret_cast<u32x4*>(p.y + orow[ps]) = qh;
             *reinterpret_cast<u32x4*>(p.y + p.ps + orow[ps]) = ql;
         }
+        RTL(4);
     }
+#ifdef YV3_RES_TL
+    if (blockIdx.x == 17 && lane == 0) {
+        float* dbg = reinterpret_cast<float*>(p.y) + wid * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = (float)tl_acc[i];
+        dbg[6] = (float)((p.total - 17 + gridDim.x - 1) / gridDim.x);
+    }
+#endif
     if (p.flags && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.flags, 1);
 }
 
