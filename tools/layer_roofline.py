@@ -29,6 +29,11 @@ for (cin, cout, k, s, H, tile), n, ms in rows:
         flops += 2.0 * B * hin * hin * 32 * 27
     out_bytes = M * cout * 4
     w_bytes = cout * cin * k * k * 4
+    if str(tile).startswith("conv_res64"):                             # fused residual block: x (64 ch) read once (input AND residual), 1x1 + 3x3 FLOPs
+        in_bytes = M * 64 * 4
+        flops += 2.0 * M * 32 * 64
+        w_bytes += 32 * 64 * 4
+        res = False
     byts = in_bytes + out_bytes + w_bytes + (out_bytes if res else 0)
     t_f, t_b = flops / PEAK_F * 1e3, byts / PEAK_B * 1e3
     roof = max(t_f, t_b)

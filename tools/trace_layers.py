@@ -6,24 +6,24 @@ from yolo_v3_amd import arch
 path, B, size = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-convs = [r for r in rows if "conv_igemm" in r["Kernel_Name"] or "conv0_" in r["Kernel_Name"] or "conv_planes" in r["Kernel_Name"]
-         or "conv_front" in r["Kernel_Name"]]
-fused = any("conv_front" in r["Kernel_Name"] for r in convs)       # first two layers in one launch
-per_step = 74 if fused else 75
+NAMES = ("conv_igemm", "conv0_", "conv_planes", "conv_front", "conv_res64")
+convs = [r for r in rows if any(n in r["Kernel_Name"] for n in NAMES)]
+fused_front = any("conv_front" in r["Kernel_Name"] for r in convs)      # feature.mlist.0 + .1 in one launch
+fused_res = any("conv_res64" in r["Kernel_Name"] for r in convs)        # feature.mlist.2 (1x1 + 3x3 + add) in one launch
+specs = arch.conv_specs(); hw = arch.conv_output_hw(size)
+groups_of = ([[0, 1]] if fused_front else [[0], [1]]) + ([[2, 3]] if fused_res else [[2], [3]]) + [[i] for i in range(4, len(specs))]
+per_step = len(groups_of)
 nsteps = len(convs) // per_step
 last = convs[(nsteps - 1) * per_step: nsteps * per_step]
-specs = arch.conv_specs(); hw = arch.conv_output_hw(size)
-if fused:                                                          # merge spec 0 into spec 1: FLOPs of both, shape of the second
-    f0 = 2.0 * hw[0][0] * hw[0][1] * specs[0].cout * specs[0].cin * 9 * B
-    specs, hw = specs[1:], hw[1:]
 tot = 0.0; totf = 0.0
 groups = {}
-for r, sp, (h, w) in zip(last, specs, hw):
+for r, idxs in zip(last, groups_of):
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-    fl = 2.0 * h * w * sp.cout * sp.cin * sp.k * sp.k * B
-    kn = r["Kernel_Name"]; cfg = kn[kn.find("<"):kn.find(">") + 1] if "<" in kn else ("conv_front (3->32 + 32->64 s2)" if "conv_front" in kn else "conv0")
-    if "conv_front" in kn:
-        fl += f0
+    fl = sum(2.0 * hw[i][0] * hw[i][1] * specs[i].cout * specs[i].cin * specs[i].k * specs[i].k * B for i in idxs)
+    sp, (h, w) = specs[idxs[-1]], hw[idxs[-1]]
+    kn = r["Kernel_Name"]
+    cfg = ("conv_front (3->32 + 32->64 s2)" if "conv_front" in kn else "conv_res64 (64->32 1x1 + 32->64 3x3 + add)" if "conv_res64" in kn
+           else kn[kn.find("<"):kn.find(">") + 1] if "<" in kn else "conv0")
     key = (sp.cin, sp.cout, sp.k, sp.stride, h, cfg)
     g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
     tot += dur; totf += fl
