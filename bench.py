@@ -13,7 +13,7 @@ GPU (weak scaling, the default), --global-batch fixes the total (strong scaling;
 Rank 0 prints ONE JSON line.
 
 `roofline` is for the dominant kernel family, the implicit-GEMM convolution (conv_planes_kernel<2,...> in the default
-fp16x2-plane mode: 73 launches per step behind the fused two-layer front kernel, 74 in the other modes): algorithmic FLOPs
+fp16x2-plane mode: 71 launches per step behind the two fused front kernels -- first two layers, first residual block -- and 74 in the other modes): algorithmic FLOPs
 (2*MAC) of those convs for the batch divided by the duration of their launch sequence, measured with HIP events on the
 launch stream in every timed step (`all_75_convs_frac`: all 75 convs over front + convs time).  In the
 default mode each fp32 product costs 3 fp16 MFMAs, so the peak for ALGORITHMIC FLOP/s is 2500/3 TFLOP/s and `frac`
@@ -163,8 +163,9 @@ class Workload:
         specs = arch.conv_specs()
         hw = arch.conv_output_hw(self.size)
         macs = [h * w * sp.cout * sp.cin * sp.k * sp.k for sp, (h, w) in zip(specs, hw)]
-        first = 1 + self.det.plan.first_desc
-        return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, len(macs) - first
+        plan = self.det.plan
+        first = 1 + plan.first_desc
+        return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, plan.n_desc - plan.first_desc
 
     def summary(self, elapsed, steps):
         st = self.stages_ms()
@@ -233,6 +234,9 @@ def main():
 
     main_w = Workload(net, x, args.dtype, args.conf, args.nms, world=world)
     elapsed = main_w.run(args.steps, args.warmup)
+    if rank == 0 and os.environ.get("YV3_DUMP_PLAN"):               # for tools/trace_layers.py: conv spec index of every launch
+        p_ = main_w.det.plan
+        json.dump({"first_desc": p_.first_desc, "desc_spec": p_.desc_spec}, open(os.environ["YV3_DUMP_PLAN"], "w"))
     head = main_w.summary(elapsed, args.steps)
     kept4 = main_w.host_counts[B:B + 4].tolist()                       # rank 0's shard: [0:B] candidates, [B:2B] kept
 

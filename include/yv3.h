@@ -157,6 +157,11 @@ typedef struct yv3_conv_desc {
     int       big_tile_min;           /* plane kernels: minimum number of 256x128 tiles for which that tile is
                                          used instead of 128x128 (0: default 128 = half a round of the chip) */
     int       tune[4];                /* kernel-tuning experiments (0 = off); meaning private to the kernels */
+    /* Plane strides in ELEMENTS for plane dtypes, 0 = the packed default B*H*W*C of that tensor.  They let one launch work
+       on a batch SLICE of [NP][B_total,H,W,C] tensors (x / x2 / y + residual: base pointers offset by b0*H*W*C, B = slice
+       size, strides = those of the full tensors): the engine runs a layer whose tiles fill between one and two rounds of the
+       chip as "exactly one round" + "the rest" (bit-identical results: the K order does not depend on the tiling). */
+    long long x_plane_stride, x2_plane_stride, y_plane_stride;
 } yv3_conv_desc;
 
 #define YV3_OPT_NO_PINGPONG 1u    /* fp16-plane 8-wave tiles: single-phase main loop instead of the two-group ping-pong */

@@ -98,7 +98,7 @@ def teacher_forced_layers(net, mode, x, taps):
             out[eng.specs[0].name] = (get(eng.specs[0].name), tapd[eng.specs[0].name])
             for j in range(plan.n_desc):
                 d = plan.descs[j]
-                name = eng.specs[j + 1].name
+                name = eng.specs[plan.desc_spec[j]].name          # (a layer may be two launches over batch slices)
                 for ptr in (d.x, d.x2, d.residual):
                     put(ptr)
                 _ffi.check(_ffi.lib().yv3_conv2d(ctypes.byref(d), _ffi.stream_ptr()), "yv3_conv2d " + name)

@@ -12,6 +12,10 @@ fused_front = any("conv_front" in r["Kernel_Name"] for r in convs)      # featur
 fused_res = any("conv_res64" in r["Kernel_Name"] for r in convs)        # feature.mlist.2 (1x1 + 3x3 + add) in one launch
 specs = arch.conv_specs(); hw = arch.conv_output_hw(size)
 groups_of = ([[0, 1]] if fused_front else [[0], [1]]) + ([[2, 3]] if fused_res else [[2], [3]]) + [[i] for i in range(4, len(specs))]
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):              # bench.py's YV3_DUMP_PLAN: a layer may be two launches (batch split)
+    import json
+    pl = json.load(open(sys.argv[4]))
+    groups_of = (([[0, 1]] + ([[2, 3]] if fused_res else [])) if fused_front else [[0]]) + [[i] for i in pl["desc_spec"][pl["first_desc"]:]]
 per_step = len(groups_of)
 nsteps = len(convs) // per_step
 last = convs[(nsteps - 1) * per_step: nsteps * per_step]

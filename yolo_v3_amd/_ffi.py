@@ -28,7 +28,8 @@ class ConvDesc(ctypes.Structure):
                 ("dtype", c_int), ("out_dtype", c_int), ("flags", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("dec_out", c_void_p), ("dec_out_batch_stride", c_longlong), ("dec_stride", c_float),
-                ("dec_anchors", c_float * 6), ("options", ctypes.c_uint), ("big_tile_min", c_int), ("tune", c_int * 4)]
+                ("dec_anchors", c_float * 6), ("options", ctypes.c_uint), ("big_tile_min", c_int), ("tune", c_int * 4),
+                ("x_plane_stride", c_longlong), ("x2_plane_stride", c_longlong), ("y_plane_stride", c_longlong)]
 
 
 _SIGNATURES = {

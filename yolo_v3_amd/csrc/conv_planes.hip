@@ -653,6 +653,9 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         p.x2s = 0;
     }
     p.ys = M * d->cout;
+    if (d->x_plane_stride > 0) p.xs = d->x_plane_stride;            // batch slices of larger plane tensors
+    if (d->x2_plane_stride > 0) p.x2s = d->x2_plane_stride;
+    if (d->y_plane_stride > 0) p.ys = d->y_plane_stride;
     const bool out_f32 = d->out_dtype == YV3_F32;
     if (!out_f32 && (d->cout % 8)) return YV3_ESHAPE;
     const int npad = d->cout_pad;

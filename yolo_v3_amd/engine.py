@@ -127,7 +127,30 @@ def tuning_options():
     return opts, int(os.environ.get("YV3_BIG_MIN", "0") or 0)
 
 
-def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None):
+def batch_split(B, ho, wo, cout_pad, ncu):
+    """(B0, B1) when a 3x3 plane-kernel launch should run as two: its 256x128 tiles fill between one and two rounds of the
+    chip's `ncu` CUs with a partial second round of 15-60 % -- then the first B0 images fill (at most) exactly one round and the
+    remaining B1 run on their own.  Measured in the network at bs=64 (profiles/r02_batch_split_probe.log, r02e layer table):
+    the 13x13 layers (344 tiles = 1.34 rounds) 0.311 -> 0.189 + 0.091 ms; layers with more rounds do not gain.  Results are
+    bit-identical (the K order does not depend on the tiling).  None: one launch."""
+    if cout_pad % 128:
+        return None
+    ntn = cout_pad // 128
+
+    def tiles(b):
+        return -(-(b * ho * wo) // 256) * ntn
+    t = tiles(B)
+    if not (ncu < t < 2 * ncu) or not (0.15 <= t / ncu - 1.0 <= 0.6):
+        return None
+    fit = [b for b in range(1, B) if tiles(b) <= ncu]
+    if not fit:
+        return None
+    return fit[-1], B - fit[-1]
+
+
+def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None,
+              batch=None):
+    """`batch` = (b0, nb): the descriptor covers images b0 .. b0+nb-1 of the [NP][B,...] plane tensors (plane dtypes only)."""
     sp = pc.spec
     d = ConvDesc()
     d.options, d.big_tile_min = tuning_options()
@@ -145,6 +168,20 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
     d.flags = _ptr(flags)
     d.workspace = _ptr(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    if batch is not None:
+        b0, nb = batch
+        ho, wo = out_hw(H, W, sp.k, sp.stride)
+
+        def sl(t, per_img):                               # pointer to image b0 of plane 0; plane stride stays the full tensor's
+            return ctypes.c_void_p(t.data_ptr() + b0 * per_img * t.element_size()) if t is not None else None
+        cx = cin_up if cin_up else sp.cin
+        hx, wx = (H // 2, W // 2) if cin_up else (H, W)
+        d.x, d.x_plane_stride = sl(x, hx * wx * cx), B * hx * wx * cx
+        if x2 is not None:
+            d.x2, d.x2_plane_stride = sl(x2, H * W * (sp.cin - cin_up)), B * H * W * (sp.cin - cin_up)
+        d.y, d.y_plane_stride = sl(y, ho * wo * sp.cout), B * ho * wo * sp.cout
+        d.residual = sl(residual, ho * wo * sp.cout)
+        d.B = nb
     return d
 
 
@@ -184,6 +221,9 @@ class Plan:
         # materialised and the descriptors' dec_out is pointed at the caller's detections tensor before each launch
         self.fused_decode = bool(engine.fuse_decode and dt != F32)
         self.head_descs = []     # (descriptor index, ho, wo)
+        self.desc_spec = []      # descriptor index -> index into arch.conv_specs (a layer may run as two launches: batch_split)
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        ncu = ncu & ~7 if ncu >= 8 else 256
         # fp16-plane mode: feature.mlist.0 + feature.mlist.1 run as ONE launch (csrc/conv_front.hip); the first layer's
         # [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
         self.fused_front = bool(engine.fuse_front and dt == F32H2)
@@ -198,7 +238,12 @@ class Plan:
             y = None if (head and self.fused_decode) else buf(ho, wo, pc.spec.cout, dt if out_dtype is None else out_dtype)
             if head:
                 self.head_descs.append((len(descs), ho, wo))
-            descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace))
+            split = None
+            if engine.batch_split and dt == F32H2 and pc.spec.k == 3 and not head and self.workspace is None:
+                split = batch_split(B, ho, wo, pc.cout_pad, ncu)
+            for part in ([None] if split is None else [(0, split[0]), (split[0], split[1])]):
+                descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace, batch=part))
+                self.desc_spec.append(i)
             if y is not None:
                 self.layer_out[pc.spec.name] = y
             return y, ho, wo
@@ -242,7 +287,7 @@ class Plan:
         u2, _, _ = conv(i, h2, h61, w61); i += 1                                  # up2.conv (26x26)
         t36, h36, w36 = r36
         branch(u2, h36, w36, x2=t36, cin_up=packed[i - 1].spec.cout)
-        assert i == len(packed) == 75
+        assert i == len(packed) == 75 and self.desc_spec[:3] == [1, 2, 3]
 
         self._keep = keep
         self.n_desc = len(descs)
@@ -301,6 +346,7 @@ class Engine:
         self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
         self.fuse_front = bool(getattr(net, "fuse_front", os.environ.get("YV3_NO_FUSED_FRONT") is None))
         self.fuse_res64 = bool(getattr(net, "fuse_res64", os.environ.get("YV3_NO_FUSED_RES64") is None))
+        self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_NO_BATCH_SPLIT") is None))
 
     # -- weights
     def _param_tensors(self):
