@@ -395,9 +395,9 @@ def test_odd_shapes_vs_oracle(sw1_stream, stream_k):
 
 @pytest.mark.gpu
 def test_batch_split_schedule_is_bit_identical(sw1_stream):
-    """At bs=64 the 13x13 3x3 layers (344 tiles of 256x128 = 1.34 rounds of the chip) run as two launches, 48 + 16 images
-    (engine.batch_split): same kernels, same K order -> detections bit-identical to the one-launch plan; the plan really
-    contains the extra launches."""
+    """Opt-in schedule (net.batch_split): at bs=64 the 13x13 3x3 layers (344 tiles of 256x128 = 1.34 rounds of the chip) run
+    as two launches over batch slices, 48 + 16 images (yv3_conv_desc.*_plane_stride): same kernels, same K order ->
+    detections bit-identical to the one-launch plan; the plan really contains the extra launches."""
     net = load_sw1_net(sw1_stream).cuda()
     x = torch.from_numpy(synth.images(64, 416, 4243)).cuda()
     eng = net.engine()
@@ -408,6 +408,6 @@ def test_batch_split_schedule_is_bit_identical(sw1_stream):
             d, plan = eng.forward(x)
             outs.append((d.clone(), plan.n_desc))
         finally:
-            eng.batch_split, eng._plans = True, {}
+            eng.batch_split, eng._plans = False, {}
     assert outs[0][1] == 74 and outs[1][1] == 74 + 8          # the 512->1024 3x3 layers: 4 res blocks + 3 branch convs + the s2 conv
     assert torch.equal(outs[0][0], outs[1][0])

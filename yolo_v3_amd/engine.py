@@ -130,9 +130,11 @@ def tuning_options():
 def batch_split(B, ho, wo, cout_pad, ncu):
     """(B0, B1) when a 3x3 plane-kernel launch should run as two: its 256x128 tiles fill between one and two rounds of the
     chip's `ncu` CUs with a partial second round of 15-60 % -- then the first B0 images fill (at most) exactly one round and the
-    remaining B1 run on their own.  Measured in the network at bs=64 (profiles/r02_batch_split_probe.log, r02e layer table):
-    the 13x13 layers (344 tiles = 1.34 rounds) 0.311 -> 0.189 + 0.091 ms; layers with more rounds do not gain.  Results are
-    bit-identical (the K order does not depend on the tiling).  None: one launch."""
+    remaining B1 run on their own.  Opt-in (`net.batch_split = True`): in isolation the 13x13 layers at bs=64 (344 tiles =
+    1.34 rounds) take 0.349 ms as one launch and 0.219 + 0.106 ms as two (profiles/r02_batch_split_probe.log), but inside the
+    network the step time is unchanged (13.21 vs 13.21 ms, same box, alternating runs) -- the chip is power-limited, a
+    partially filled round simply clocks higher.  Results are bit-identical (the K order does not depend on the tiling).
+    None: one launch."""
     if cout_pad % 128:
         return None
     ntn = cout_pad // 128
@@ -346,7 +348,8 @@ class Engine:
         self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
         self.fuse_front = bool(getattr(net, "fuse_front", os.environ.get("YV3_NO_FUSED_FRONT") is None))
         self.fuse_res64 = bool(getattr(net, "fuse_res64", os.environ.get("YV3_NO_FUSED_RES64") is None))
-        self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_NO_BATCH_SPLIT") is None))
+        # opt-in (measured null end to end, see batch_split): 13x13 layers as "one full round" + "the rest"
+        self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_BATCH_SPLIT") == "1"))
 
     # -- weights
     def _param_tensors(self):
