@@ -180,3 +180,17 @@ def test_coco_writer_host_logic(tmp_path):
     with evaluate.open_json_pred_writer(out, None, True) as wr:
         wr.process_batch({"img": torch.zeros(1, 3, 32, 32), "org_img": [torch.zeros(3, 8, 8)], "img_path": ["x_1.jpg"]}, [torch.Tensor()])
     assert json.load(open(out)) == []
+
+
+def test_batch_split_rule():
+    """engine.batch_split (opt-in schedule): only launches whose 256x128 tiles fill 1.15-1.6 rounds of the chip are split, into
+    'at most one full round' + 'the rest'; everything else stays one launch."""
+    from yolo_v3_amd.engine import batch_split
+    assert batch_split(64, 13, 13, 1024, 256) == (48, 16)            # 344 tiles = 1.34 rounds -> 256 + 88
+    assert batch_split(64, 26, 26, 512, 256) is None                 # 2.64 rounds
+    assert batch_split(64, 52, 52, 256, 256) is None                 # 5.28 rounds
+    assert batch_split(32, 13, 13, 1024, 256) is None                # 0.69 rounds
+    assert batch_split(64, 13, 13, 255 + 1, 256) is None             # 0.34 rounds
+    assert batch_split(64, 13, 13, 96, 256) is None                  # channel count not tiled by 128
+    b0, b1 = batch_split(64, 13, 13, 1024, 256)
+    assert -(-(b0 * 169) // 256) * 8 <= 256 < -(-((b0 + 1) * 169) // 256) * 8
