@@ -688,7 +688,8 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // short-K 1x1 layers (K <= 512: 8-16 chunks per tile, mostly prologue / epilogue): two independent 4-wave workgroups
         // per CU (128x128 tiles, 2-deep ring) hide each other's IO -- in the network at bs=64 the step gains 0.8 %
         // (13.31 -> 13.20 ms, same box, alternating; K = 1024 does not gain); same K order, same bits
-        if (np == 2 && !k3 && !out_f32 && p.nk <= 16 && force == 0 && blocks256 >= big_min && p.tune[1] != 1)
+        // (the head convs at 52x52 / 26x26 included: +0.2...0.7 %; the 104x104 3x3 layers, K = 576, lose 1 % on it)
+        if (np == 2 && !k3 && p.nk <= 16 && force == 0 && blocks256 >= big_min && !(p.tune[1] & 1))
             return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         if (force == 1) return YV3_CFG(256, 128, 4, 2, 2);
         if (force == 2) return YV3_CFG(128, 128, 4, 2, 3);
