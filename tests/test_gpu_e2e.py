@@ -411,3 +411,27 @@ def test_batch_split_schedule_is_bit_identical(sw1_stream):
             eng.batch_split, eng._plans = False, {}
     assert outs[0][1] == 74 and outs[1][1] == 74 + 8          # the 512->1024 3x3 layers: 4 res blocks + 3 branch convs + the s2 conv
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,size", [(64, 416), (17, 320)])
+def test_two_lanes_are_bit_identical_to_one(sw1_stream, B, size):
+    """Detector(lanes=2): the batch as two contiguous sub-batches on two HIP streams (same kernels, same K order, one shared
+    status word) -> detections and final boxes bit-identical to the single-lane run, for an even and an odd batch; the
+    default (lanes=None) calibrates the stream pair and ends up with 1 or 2 lanes, same results either way; saturation in
+    EITHER lane is reported."""
+    net = load_sw1_net(sw1_stream, size).cuda()
+    x = torch.from_numpy(synth.images(B, size, 77)).cuda()
+    one, two, auto = (Detector(net, B, size, size, lanes=n) for n in (1, 2, None))
+    assert (one.lanes, two.lanes) == (1, 2) and auto.lanes in (1, 2)
+    assert [p.B for p in two.lane_plans] == [(B + 1) // 2, B // 2]
+    r1, r2, ra = one(x), two(x), auto(x)
+    assert torch.equal(one.dets, two.dets) and torch.equal(one.dets, auto.dets)
+    assert len(r1) == len(r2) == len(ra) == B and sum(len(b) for b in r1) > B
+    for a, b, c in zip(r1, r2, ra):
+        assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b) and torch.equal(a, c)
+    bad = x.clone()
+    bad[B - 1] *= 1e4                                           # an image of the SECOND lane leaves the fp16 range of the first layer
+    with pytest.raises(_ffi.Yv3Error, match="fp16 range"):
+        two(bad)
+    assert all(torch.equal(a, b) for a, b in zip(two(x), r1))   # and the detector is usable again afterwards

@@ -10,16 +10,29 @@ launches -> 3 decode launches writing the concatenated tensor directly -> filter
 IOU masks -> scan -> compact, with no host synchronisation until ONE device-to-host copy of the
 final ``[B, cap, 7]`` boxes and their counts.  ``Detector`` keeps the buffers (and optionally a
 captured HIP graph of the whole pipeline) alive across calls.
+
+Lanes.  A batch of 16 or more images runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
+kernels with the same K order, so the detections are bit-identical, but the two launch sequences run concurrently
+and fill each other's partially occupied rounds of the chip (at bs=64 the 13x13 layers have 1.34 rounds of tiles,
+the 26x26 layers 2.64, ...) and overlap HBM-bound layers with matrix-bound ones: conv section 13.97 -> 12.65 ms
+(tools/lanes_probe.py).  HIP maps streams onto a few hardware queues and two streams on the SAME queue serialise
+(measured: 15.1 ms, worse than one lane), so the constructor times the candidate stream pairs on this GPU and
+keeps the fastest -- or a single lane if none wins.
 """
+import time
+
 import torch
 
 from . import _ffi
+from .engine import Plan
 from .utils import PostProcessor
 
 
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
-                 max_cand=None, cap=None, dtype=None, graph=False):
+                 max_cand=None, cap=None, dtype=None, graph=False, lanes=None):
+        """lanes: 1, 2, or None = automatic (2 when batch >= 16 and a stream pair that really runs concurrently is found,
+        see the module docstring; ``net.lanes`` / YV3_LANES override the default)."""
         self.net = net
         self.shape = (batch, 3, height, width)
         self.conf, self.nms_thr, self.is_eval, self.use_nms = obj_conf_thr, nms_thr, is_eval, use_nms
@@ -27,16 +40,95 @@ class Detector:
         self.engine.ensure_packed()
         self.device = self.engine.device
         self._generation = self.engine.generation
+        if lanes is None:
+            import os
+            lanes = getattr(net, "lanes", None) or (int(os.environ["YV3_LANES"]) if os.environ.get("YV3_LANES") else None)
+        self._lanes_req = lanes
         with torch.cuda.device(self.device):
-            self.plan = self.engine.plan(batch, height, width)
+            self._build_plans(2 if (lanes is None and batch >= 16) or (lanes or 1) >= 2 else 1)
             self.dets = torch.empty((batch, self.plan.N, self.plan.attrib), device=self.device, dtype=torch.float32)
             n = self.plan.N
             self.pp = PostProcessor(batch, n, net.numClass, self.device,
                                     max_cand=max_cand or (min(n * net.numClass, 16384) if is_eval else n), cap=cap)
+            if self.lanes > 1 and lanes is None:
+                self._calibrate_lanes()
         self._graph = None
         self._static_in = None
         self._want_graph = graph
         self.boxes = None
+
+    # -- lanes
+    def _build_plans(self, lanes):
+        B, _, H, W = self.shape
+        lanes = max(1, min(int(lanes), B))
+        self.lanes = lanes
+        if lanes == 1:
+            self.plan = self.engine.plan(B, H, W)                 # the engine's cached plan (shared with net.forward)
+            self.lane_plans, self.lane_off, self.lane_streams = [self.plan], [0], []
+            return
+        sizes = [B // lanes + (1 if i < B % lanes else 0) for i in range(lanes)]
+        flags = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self.lane_plans = [Plan(self.engine, b, H, W, flags=flags) for b in sizes]     # own buffers per lane, ONE status word
+        self.lane_off = [sum(sizes[:i]) for i in range(lanes)]
+        self.lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
+        self.plan = self.lane_plans[0]
+
+    def _run_convs(self, x, mark):
+        """conv0 ... head convs (+ decode) of every lane; returns on the current stream with all lanes joined."""
+        if self.lanes == 1:
+            self.engine.run_front(self.plan, x)
+            mark("conv0")
+            self.engine.run_conv_sequence(self.plan, self.dets)
+            mark("convs")
+            self.engine.run_decode(self.plan, self.dets)
+            return
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        mark("conv0")                                             # (lanes: the front kernels are part of the 'convs' stage)
+        for p, off, st in zip(self.lane_plans, self.lane_off, self.lane_streams):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                xi, di = x[off:off + p.B], self.dets[off:off + p.B]
+                self.engine.run_front(p, xi)
+                self.engine.run_conv_sequence(p, di)
+                self.engine.run_decode(p, di)
+                done = torch.cuda.Event()
+                done.record(st)
+            main.wait_event(done)
+        mark("convs")
+
+    def _calibrate_lanes(self):
+        """Keep the stream pair that really runs the two lanes concurrently on this GPU (streams that share a hardware queue
+        serialise and LOSE against a single lane); fall back to one lane if no candidate beats it."""
+        B, _, H, W = self.shape
+        x = torch.zeros(self.shape, device=self.device, dtype=torch.float32)
+        noop = lambda name: None
+
+        def timed(n=3):
+            for _ in range(2):
+                self._run_convs(x, noop)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                self._run_convs(x, noop)
+            torch.cuda.synchronize(self.device)
+            return (time.perf_counter() - t0) / n
+
+        two_plans, two_off = self.lane_plans, self.lane_off
+        cands = [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]
+        best = None
+        for pair in cands:
+            self.lane_streams = pair
+            t = timed()
+            if best is None or t < best[0]:
+                best = (t, pair)
+        self._build_plans(1)
+        t1 = timed()
+        self.lane_calibration = {"one_lane_ms": round(t1 * 1e3, 3), "two_lanes_ms": round(best[0] * 1e3, 3)}
+        if best[0] < 0.97 * t1:
+            self.lanes, self.lane_plans, self.lane_off, self.lane_streams, self.plan = 2, two_plans, two_off, best[1], two_plans[0]
+        self.plan.flags.zero_()
 
     # -- pipeline pieces (all asynchronous on the current stream)
     def _enqueue(self, x, mark=None):
@@ -44,11 +136,7 @@ class Detector:
         stream there: per-stage split conv0 / convs / decode / filter / nms)."""
         mark = mark or (lambda name: None)
         mark("start")
-        self.engine.run_front(self.plan, x)
-        mark("conv0")
-        self.engine.run_conv_sequence(self.plan, self.dets)
-        mark("convs")
-        self.engine.run_decode(self.plan, self.dets)
+        self._run_convs(x, mark)
         mark("decode")
         # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
         self.pp.filter(self.dets, self.conf, self.is_eval, prob=True)
@@ -77,9 +165,12 @@ class Detector:
             raise _ffi.Yv3Error("Detector was built for %s, got %s" % (self.shape, tuple(x.shape)))
         with torch.cuda.device(self.device):
             self.engine.ensure_packed()
-            if self.engine.generation != self._generation:      # parameters changed: packed weights / plan were rebuilt
+            if self.engine.generation != self._generation:      # parameters changed: packed weights / plans were rebuilt
                 self._generation = self.engine.generation
-                self.plan = self.engine.plan(self.shape[0], self.shape[2], self.shape[3])
+                streams = self.lane_streams
+                self._build_plans(self.lanes)
+                if streams:
+                    self.lane_streams = streams                 # keep the calibrated pair
                 self._graph = None
             if self._want_graph:
                 if self._graph is None:

@@ -195,7 +195,7 @@ def out_hw(h, w, k, stride):
 class Plan:
     """Buffers + kernel descriptors for one (B, H, W)."""
 
-    def __init__(self, engine, B, H, W):
+    def __init__(self, engine, B, H, W, flags=None):
         if H % 32 or W % 32:
             raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
         self.B, self.H, self.W = B, H, W
@@ -206,7 +206,7 @@ class Plan:
         keep = []            # every buffer the descriptors point to
         descs = []
         # sticky status word written by the kernels (bit 0: an fp16-plane output was saturated) + its host mirror
-        self.flags = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.flags = flags if flags is not None else torch.zeros(1, device=dev, dtype=torch.int32)   # (lanes of one Detector share one)
         self.flags_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flags_event = None
         # scratch of the stream-K schedule (fp16-plane kernels): zero-filled once, one per plan (= per launch stream)
