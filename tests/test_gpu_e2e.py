@@ -435,30 +435,3 @@ def test_two_lanes_are_bit_identical_to_one(sw1_stream, B, size):
     with pytest.raises(_ffi.Yv3Error, match="fp16 range"):
         two(bad)
     assert all(torch.equal(a, b) for a, b in zip(two(x), r1))   # and the detector is usable again afterwards
-
-
-@pytest.mark.gpu
-def test_pipelined_calls_equal_plain_calls(sw1_stream):
-    """run_device(..., input_ready=True): consecutive calls overlap (the next call's convolutions start while the previous
-    call's filter / NMS / copies run; two alternating detections buffers).  Five different batches back to back, results copied
-    out in stream order, must equal the plain calls bit for bit."""
-    net = load_sw1_net(sw1_stream).cuda()
-    B = 32
-    det = Detector(net, B, 416, 416, lanes=2)
-    xs = [torch.from_numpy(synth.images(B, 416, 500 + i)).cuda() for i in range(5)]
-    want = []
-    for x in xs:
-        b, c = det.run_device(x)
-        want.append((b.clone(), c.clone(), det.dets.clone()))
-    torch.cuda.synchronize()
-    got = []
-    for x in xs:                                                   # no host sync in between: the calls pipeline
-        b, c = det.run_device(x, input_ready=True)
-        got.append((b.clone(), c.clone(), det.dets.clone()))       # clones are ordered on the current stream, like a D2H copy
-    torch.cuda.synchronize()
-    for (b0, c0, d0), (b1, c1, d1) in zip(want, got):
-        assert torch.equal(c0, c1) and torch.equal(d0, d1)
-        kept = c0[B:].tolist()
-        for i in range(B):
-            assert torch.equal(b0[i, :kept[i]], b1[i, :kept[i]])
-    assert int(det.plan.flags.item()) == 0

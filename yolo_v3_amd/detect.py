@@ -47,8 +47,6 @@ class Detector:
         with torch.cuda.device(self.device):
             self._build_plans(2 if (lanes is None and batch >= 16) or (lanes or 1) >= 2 else 1)
             self.dets = torch.empty((batch, self.plan.N, self.plan.attrib), device=self.device, dtype=torch.float32)
-            # second detections buffer + "free again" events for pipelined calls (run_device(..., input_ready=True))
-            self._dets2, self._buf_free, self._step = [self.dets, None], [None, None], 0
             n = self.plan.N
             self.pp = PostProcessor(batch, n, net.numClass, self.device,
                                     max_cand=max_cand or (min(n * net.numClass, 16384) if is_eval else n), cap=cap)
@@ -75,9 +73,8 @@ class Detector:
         self.lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
         self.plan = self.lane_plans[0]
 
-    def _run_convs(self, x, mark, fork=None):
-        """conv0 ... head convs (+ decode) of every lane; returns on the current stream with all lanes joined.
-        `fork`: event the lanes wait for instead of the current stream's position (pipelined calls); False: nothing."""
+    def _run_convs(self, x, mark):
+        """conv0 ... head convs (+ decode) of every lane; returns on the current stream with all lanes joined."""
         if self.lanes == 1:
             self.engine.run_front(self.plan, x)
             mark("conv0")
@@ -86,13 +83,11 @@ class Detector:
             self.engine.run_decode(self.plan, self.dets)
             return
         main = torch.cuda.current_stream()
-        if fork is None:
-            fork = torch.cuda.Event()
-            fork.record(main)
+        fork = torch.cuda.Event()
+        fork.record(main)
         mark("conv0")                                             # (lanes: the front kernels are part of the 'convs' stage)
         for p, off, st in zip(self.lane_plans, self.lane_off, self.lane_streams):
-            if fork is not False:
-                st.wait_event(fork)
+            st.wait_event(fork)
             with torch.cuda.stream(st):
                 xi, di = x[off:off + p.B], self.dets[off:off + p.B]
                 self.engine.run_front(p, xi)
@@ -136,34 +131,18 @@ class Detector:
         self.plan.flags.zero_()
 
     # -- pipeline pieces (all asynchronous on the current stream)
-    def _enqueue(self, x, mark=None, input_ready=False):
+    def _enqueue(self, x, mark=None):
         """`mark(name)`, if given, is called at every stage boundary (bench.py records a HIP event on the launch
         stream there: per-stage split conv0 / convs / decode / filter / nms)."""
         mark = mark or (lambda name: None)
         mark("start")
-        pipelined = bool(input_ready) and self.lanes > 1
-        if pipelined:
-            # The caller vouches that `x` is complete (resident input, e.g. a serving loop's previous H2D has been waited
-            # for): the lanes then do not wait for the current stream's position -- i.e. not for the PREVIOUS call's filter /
-            # NMS / result copies still queued on it -- but only for the detections buffer they write to be free again
-            # (two buffers alternate; post-processing of call k reads buffer k % 2 while the lanes of call k+1 fill the other)
-            k = self._step % 2
-            if self._dets2[k] is None:
-                self._dets2[k] = torch.empty_like(self._dets2[0])
-            self.dets = self._dets2[k]
-            self._run_convs(x, mark, fork=self._buf_free[k] if self._buf_free[k] is not None else False)
-        else:
-            self._run_convs(x, mark)
+        self._run_convs(x, mark)
         mark("decode")
         # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
         self.pp.filter(self.dets, self.conf, self.is_eval, prob=True)
         mark("filter")
         self.boxes = self.pp.nms(self.dets, self.nms_thr, self.use_nms, self.pp.max_cand, self.pp.cap)
         mark("nms")
-        if pipelined:
-            self._buf_free[self._step % 2] = torch.cuda.Event()
-            self._buf_free[self._step % 2].record()
-            self._step += 1
 
     def _capture(self, x):
         self._static_in = torch.empty_like(x)
@@ -179,13 +158,8 @@ class Detector:
             self._enqueue(self._static_in)
         self._graph = g
 
-    def run_device(self, imgs, mark=None, input_ready=False):
-        """Enqueue one batch; returns (boxes [B,cap,7], counts [2B]) still on the GPU, no sync.
-
-        input_ready=True (pipelined serving loops; needs two lanes, ignored in graph mode): `imgs` is already complete on the
-        device, so the convolutions of THIS call may start while the previous call's filter / NMS / result copies are still
-        running on the current stream (its detections live in the other of two alternating buffers).  The returned tensors
-        are valid in stream order as usual; `self.dets` is the buffer of the latest call."""
+    def run_device(self, imgs, mark=None):
+        """Enqueue one batch; returns (boxes [B,cap,7], counts [2B]) still on the GPU, no sync."""
         x = self.engine.prepare_input(imgs)
         if tuple(x.shape) != self.shape:
             raise _ffi.Yv3Error("Detector was built for %s, got %s" % (self.shape, tuple(x.shape)))
@@ -204,7 +178,7 @@ class Detector:
                 self._static_in.copy_(x)
                 self._graph.replay()
             else:
-                self._enqueue(x, mark, input_ready)
+                self._enqueue(x, mark)
         return self.boxes, self.pp.counts
 
     def __call__(self, imgs):
