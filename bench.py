@@ -7,7 +7,8 @@
 A step = one pass of the whole hot path over one batch of synthetic images already resident in HBM, run through
 the PRODUCT entry point `Detector.run_device` (yolo_v3_amd/detect.py: conv0 -> 74 convs with the YOLO decode fused
 into the head convs -> confidence filter -> per-class greedy NMS), then the final [B,cap,7] boxes + counts are
-copied to pinned host memory asynchronously.  With N > 1 (torch.distributed.run, one rank per GPU) every rank runs
+copied to pinned host memory asynchronously.  For batches >= 16 the Detector runs the convolutions as two sub-batches
+on two concurrent HIP streams ("lanes": same kernels and bits, they fill each other's idle CUs; --lanes 1 disables).  With N > 1 (torch.distributed.run, one rank per GPU) every rank runs
 its shard and each step ends with the RCCL all-gather of the final boxes (yolo_v3_amd/dist.py); --batch is images PER
 GPU (weak scaling, the default), --global-batch fixes the total (strong scaling; BASELINE configs[3] = 256 over 8).
 Rank 0 prints ONE JSON line.
@@ -17,7 +18,10 @@ fp16x2-plane mode: 71 launches per step behind the two fused front kernels -- fi
 (2*MAC) of those convs for the batch divided by the duration of their launch sequence, measured with HIP events on the
 launch stream in every timed step (`all_75_convs_frac`: all 75 convs over front + convs time).  In the
 default mode each fp32 product costs 3 fp16 MFMAs, so the peak for ALGORITHMIC FLOP/s is 2500/3 TFLOP/s and `frac`
-is the utilisation of the 16-bit matrix pipe.  `stages_ms` is the per-stage split from the same events.
+is the utilisation of the 16-bit matrix pipe.  It is measured with ONE lane (the kernels alone on the chip: with two
+concurrent lanes a kernel's duration includes the time it shares the chip, and rocprofv3's per-kernel durations sum to
+~2x the wall time); `roofline.two_lanes_conv_section` is the rate of the conv section as the timed step runs it (all 75
+convs' FLOPs over the fork -> join wall time).  `stages_ms` is the per-stage split of the timed step from HIP events.
 
 Extra objects on the same line (rank 0, N = 1; --no-extras skips them):
   cpu_baseline   the CPU oracle (oracle/oracle_cpu.py: the reference path restated in torch fp32 CPU ops) timed on this
