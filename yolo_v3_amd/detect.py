@@ -11,7 +11,7 @@ IOU masks -> scan -> compact, with no host synchronisation until ONE device-to-h
 final ``[B, cap, 7]`` boxes and their counts.  ``Detector`` keeps the buffers (and optionally a
 captured HIP graph of the whole pipeline) alive across calls.
 
-Lanes.  A batch of 16 or more images runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
+Lanes.  A batch of about 12 or more 416 x 416 images (8 at 608 x 608) runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
 kernels with the same K order, so the detections are bit-identical, but the two launch sequences run concurrently
 and fill each other's partially occupied rounds of the chip (at bs=64 the 13x13 layers have 1.34 rounds of tiles,
 the 26x26 layers 2.64, ...) and overlap HBM-bound layers with matrix-bound ones: conv section 13.97 -> 12.65 ms
@@ -31,8 +31,8 @@ from .utils import PostProcessor
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
                  max_cand=None, cap=None, dtype=None, graph=False, lanes=None):
-        """lanes: 1, 2, or None = automatic (2 when batch >= 16 and a stream pair that really runs concurrently is found,
-        see the module docstring; ``net.lanes`` / YV3_LANES override the default)."""
+        """lanes: 1, 2, or None = automatic (2 when the batch is at least ~12 images of 416 x 416 and a stream pair that really
+        runs concurrently is found, see the module docstring; ``net.lanes`` / YV3_LANES override the default)."""
         self.net = net
         self.shape = (batch, 3, height, width)
         self.conf, self.nms_thr, self.is_eval, self.use_nms = obj_conf_thr, nms_thr, is_eval, use_nms
@@ -45,7 +45,9 @@ class Detector:
             lanes = getattr(net, "lanes", None) or (int(os.environ["YV3_LANES"]) if os.environ.get("YV3_LANES") else None)
         self._lanes_req = lanes
         with torch.cuda.device(self.device):
-            self._build_plans(2 if (lanes is None and batch >= 16) or (lanes or 1) >= 2 else 1)
+            # automatic: worth trying from ~12 images of 416 x 416 upwards (measured crossover; 608 x 608: 8), calibration decides
+            auto2 = lanes is None and batch >= 2 and batch * height * width >= 12 * 416 * 416
+            self._build_plans(2 if auto2 or (lanes or 1) >= 2 else 1)
             self.dets = torch.empty((batch, self.plan.N, self.plan.attrib), device=self.device, dtype=torch.float32)
             n = self.plan.N
             self.pp = PostProcessor(batch, n, net.numClass, self.device,
