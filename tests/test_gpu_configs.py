@@ -381,3 +381,24 @@ def test_eval_mode_at_reference_thresholds(golden_dir):
     evaluate.predict_and_process([sample], net, 80, rec)           # defaults == the reference's 0.005 / 0.45
     for a, b in zip(rec.pred, res):
         assert torch.equal(a, b)
+
+
+def test_decision_flip_rate_on_unselected_scenes(net, sw1_sd):
+    """"NMS boxes delta vs ref" on inputs that were NOT selected for their decision margins: 96 synthetic scenes (seeds
+    9000..9002 x 32 images), default math mode, whole pipeline (two lanes) against the oracle's.  Every confidence / argmax /
+    IOU decision that sits inside fp32 noise of its threshold may flip; measured: 0 of ~7.7 k boxes.  Asserted: <= 0.5 % of
+    the boxes unmatched (class + IOU >= 0.999), matched boxes within 1e-4."""
+    tot = dict(ref=0, got=0, unmatched=0, coords=0.0, score=0.0, images_equal=0)
+    for seed in (9000, 9001, 9002):
+        x = torch.from_numpy(synth.images(32, 416, seed))
+        with torch.no_grad():
+            want = oc.detect(sw1_sd, x, 80, 0.5, 0.4)
+        got = detect(net, x.cuda(), 80, 0.5, 0.4)
+        d = boxes_delta(got, want, 32)
+        tot["ref"] += d["ref_boxes"]; tot["got"] += d["got_boxes"]; tot["unmatched"] += d["unmatched_ref"] + d["unmatched_got"]
+        tot["coords"] = max(tot["coords"], d["max_rel_err_coords"]); tot["score"] = max(tot["score"], d["max_abs_err_score"])
+        tot["images_equal"] += d["class_equal_images"]
+    print("decision flips on 96 unselected scenes:", tot)
+    assert tot["ref"] > 5000
+    assert tot["unmatched"] <= 0.005 * (tot["ref"] + tot["got"])
+    assert tot["coords"] <= TOL and tot["score"] <= TOL
