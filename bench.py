@@ -257,8 +257,10 @@ def main():
     # durations that sum to ~2x the wall time).  The two-lane conv-section rate (FLOPs over wall) is reported next to it.
     lanes_used = main_w.det.lanes
     roof_w, head1 = main_w, head
-    if lanes_used > 1:
-        roof_w = Workload(net, x, args.dtype, args.conf, args.nms, world=world, lanes=1)
+    if lanes_used > 1 and rank == 0:
+        # rank-local (world=1: no collective inside) -- whether a rank runs two lanes is ITS calibration's decision, so a pass
+        # with barriers here could leave the ranks waiting for each other
+        roof_w = Workload(net, x, args.dtype, args.conf, args.nms, world=1, lanes=1)
         e1 = roof_w.run(min(args.steps, 10), 3)
         head1 = roof_w.summary(e1, min(args.steps, 10))
     out = None

@@ -10,6 +10,8 @@ LAYERS = {  # name: cin, cout, k, stride, H (input), res
     "c104": (64, 128, 3, 1, 104, True), "c208": (32, 64, 3, 1, 208, True), "d208": (32, 64, 3, 2, 416, False),
     "p26": (512, 256, 1, 1, 26, False), "p52": (256, 128, 1, 1, 52, False), "p13": (1024, 512, 1, 1, 13, False),
     "p104": (128, 64, 1, 1, 104, False), "p208": (64, 32, 1, 1, 208, False),
+    "g8k": (8192, 8192, 1, 1, 32, False),   # with BB=8: the 8192^3 GEMM of tools/gemm_ceiling_probe.py as a 1x1 layer (x3 MFMAs)
+    "g4k3": (4096, 4096, 3, 1, 16, False),  # with BB=32: M=8192, N=4096, K=36864 through the 3x3 gather
     "L52": (512, 256, 3, 1, 52, True),      # long-K probe (K=4608): loop efficiency without prologue/epilogue weight
 }
 B = int(os.environ.get("BB", "64"))

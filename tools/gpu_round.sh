@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU session: tests, bench line, rocprofv3 kernel stats, PMC passes (MFMA util, FETCH, WRITE).  Usage:
-#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r02a [tests] [bench] [prof] [pmc]'
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r02a [tests] [bench] [prof] [pmc] [rehearse]'
 TAG=$1; shift
 WHAT="${@:-tests bench prof pmc}"
 export TMPDIR=/tmp
@@ -20,4 +20,7 @@ pmc)   for c in MFMA FETCH WRITE; do
        python tools/mfma_util_summary.py $O/${TAG}_pmc_MFMA > $O/${TAG}_mfma_util.json; cat $O/${TAG}_mfma_util.json | head -60
        python tools/traffic_summary.py $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE 4 71 > $O/${TAG}_traffic_f32h2_416_bs64.json; cat $O/${TAG}_traffic_f32h2_416_bs64.json
        rm -rf $O/${TAG}_pmc_MFMA $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE ;;
+rehearse) # the driver's N>1 launch line with 2 ranks on this ONE GPU (gloo carries the gather: RCCL refuses two ranks per device)
+       YV3_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+           bench.py --gpus 2 --steps 10 --warmup 3 > $O/${TAG}_bench_2rank_gloo_rehearsal.json 2> $O/${TAG}_rehearse.err; tail -c 400 $O/${TAG}_bench_2rank_gloo_rehearsal.json; tail -2 $O/${TAG}_rehearse.err ;;
 esac; done
