@@ -9,14 +9,18 @@
 // A is never materialised: NHWC activations make every 32-wide K chunk of one output pixel a
 // contiguous 128-byte run of the input at pixel (ho*s+kh-pad, wo*s+kw-pad) (or zeros in the
 // halo), so a tile row is fetched with eight coalesced 16-byte loads.  Tiles are staged through
-// LDS (row pitch 36 floats: conflict-free ds_read_b128 of MFMA fragments) with register prefetch
-// of the next K chunk + a double-buffered LDS image, one barrier per chunk.
-// Math: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate == an fmaf chain, 157 TFLOP/s peak).
-// Epilogue: BN scale/shift (or bias), LeakyReLU(0.1), residual add, straight from the
-// accumulators as 128-byte row segments.
+// LDS (row pitch 36 floats: conflict-free ds_read_b128 of MFMA fragments): two register sets prefetch
+// the next TWO K chunks (every load unconditional -> exact vmcnt waits), double-buffered LDS image,
+// one barrier per chunk; 128x128 tiles run with eight waves (four per SIMD with two workgroups per CU).
+// Math: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate == an fmaf chain, 157 TFLOP/s peak; measured on
+// this part with operands in registers and nothing else going on: 156 TFLOP/s on zeros, 136-144 on random
+// data, tools/probes/mfma_f32_mix.hip).
+// Epilogue: BN scale/shift (or bias), LeakyReLU(0.1), residual add: through LDS as 16-byte row segments
+// with the residual reads batched; straight from the accumulators for the 255-channel head convs.
 //
 // Replaces reference darknet.py:43-44 (conv_bn_relu.forward), :52-53 (res_layer.forward),
 // :118 (plain head conv) and :161-162 (nearest x2 upsample + cat, folded into the A gather).
+#include <type_traits>
 #include "yv3_common.h"
 
 namespace {
@@ -37,15 +41,64 @@ struct ConvParams {
     int ntiles;        // N tiles
 };
 
+__device__ __attribute__((aligned(16))) float g_zero_f32[4];      // zero-initialised; NOT const: a constant-address-space pointer would turn the loads into flat_load
+
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;     // floats per LDS row: 32 + 4 pad -> 144-byte pitch
 
+// Epilogue through LDS (cout % 4 == 0 and the wave's channel range inside cout): BN scale/shift and LeakyReLU on the
+// accumulators, the wave's WTM x WTN tile into its own LDS region, then 16-byte row segments with the residual added --
+// residual reads are issued as one batch (the straight-from-accumulator epilogue below issues them one dependent dword at a
+// time: ~30 us per 256 x 128 tile).  Same operation order: same bits.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <int MT, int NT>
+__device__ inline void epilogue_lds(const f32x16 (&acc)[MT][NT], const ConvParams& p, float* tile, int mw, int nw, int lane) {
+    constexpr int WTM = MT * 32, WTN = NT * 32, EP = WTN + 4;
+    constexpr int LPR = WTN / 4, RPP = 64 / LPR, NPASS = WTM / RPP;     // lanes per row, rows per pass, passes
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = nw + j * 32 + l31;
+        const float al = p.alpha ? p.alpha[n] : 1.f;
+        const float be = p.beta[n];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = fmaf(acc[i][j][e], al, be);
+                if (p.act == YV3_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+                tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi) * EP + j * 32 + l31] = v;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int er = lane / LPR, ec = (lane % LPR) * 4;
+    f32x4 rres[NPASS];
+    if (p.res) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int m = mw + ps * RPP + er;
+            rres[ps] = *reinterpret_cast<const f32x4*>(p.res + (long long)(m < p.M ? m : p.M - 1) * p.Cout + nw + ec);
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int r = ps * RPP + er;
+        const int m = mw + r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * EP + ec);
+        if (p.res) { v[0] += rres[ps][0]; v[1] += rres[ps][1]; v[2] += rres[ps][2]; v[3] += rres[ps][3]; }
+        if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (long long)m * p.Cout + nw + ec) = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool K3, bool DUAL>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const ConvParams p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;      // 32x32 MFMA tiles per wave
-    constexpr int AR = BM / 32, BR = BN / 32;        // staging rows per thread
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int SR = 8 * WM * WN;                  // rows staged per pass: 8 threads (float4 each) per 32-float row
+    constexpr int AR = BM / SR, BR = BN / SR;        // staging rows per thread
+    static_assert(BM % SR == 0 && BN % SR == 0, "staging passes");
     static_assert(MT >= 1 && NT >= 1, "wave tile must hold a 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -60,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int lrow = tid >> 3;      // 0..31
+    const int lrow = tid >> 3;      // 0..SR-1
     const int lc4 = tid & 7;        // float4 column within the 32-float chunk
 
     // ---- per-thread A row descriptors (AR rows, 32 apart)
@@ -71,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-        const int m = m0 + lrow + 32 * r;
+        const int m = m0 + lrow + SR * r;
         aok[r] = m < p.M;
         const int mm = aok[r] ? m : 0;
         const int b = mm / HoWo;
@@ -93,15 +146,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     // ---- per-thread B row offsets
     long long boff[BR];
 #pragma unroll
-    for (int r = 0; r < BR; ++r) boff[r] = (long long)(n0 + lrow + 32 * r) * p.K + lc4 * 4;
+    for (int r = 0; r < BR; ++r) boff[r] = (long long)(n0 + lrow + SR * r) * p.K + lc4 * 4;
 
-    f32x4 ra[AR], rb[BR];
+    // two register sets: chunk c is requested at the top of iteration c-2 and moved to LDS at the bottom of iteration c-1,
+    // so a global load has two compute phases to land
+    f32x4 ra[2][AR], rb[2][BR];
     int kh = 0, kw = 0, c0 = 0;          // walking (tap, channel) position of the chunk being loaded
 
-    auto load_chunk = [&](int kc) {
+    // Every load is issued unconditionally -- halo / tail rows read a zero page, chunks past the end the zero page and the
+    // last weight chunk (never used) -- so each call is exactly AR + BR load instructions and the compiler's s_waitcnt before
+    // the LDS write of one staging set is vmcnt(AR + BR), not vmcnt(0): the other, younger set stays in flight.
+    auto load_chunk = [&](auto set_, int kc_req) {
+        constexpr int S = decltype(set_)::value;
+        const bool valid = kc_req < p.nk;
+        const int kc = valid ? kc_req : p.nk - 1;
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            bool ok = aok[r];
+            bool ok = aok[r] && valid;
             const float* src = p.x;
             long long off;
             if (K3) {
@@ -113,26 +174,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             } else {
                 off = aoff[r] + c0;
             }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(src + off);
-            ra[r] = v;
+            ra[S][r] = *reinterpret_cast<const f32x4*>(ok ? src + off : g_zero_f32);
         }
 #pragma unroll
         for (int r = 0; r < BR; ++r)
-            rb[r] = *reinterpret_cast<const f32x4*>(p.w + boff[r] + (long long)kc * BK);
+            rb[S][r] = *reinterpret_cast<const f32x4*>(p.w + boff[r] + (long long)kc * BK);
         // advance the walking position
         c0 += BK;
         if (c0 == p.Cin) { c0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](auto set_, int buf) {
+        constexpr int S = decltype(set_)::value;
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int r = 0; r < AR; ++r)
-            *reinterpret_cast<f32x4*>(a + (lrow + 32 * r) * LDS_LD + lc4 * 4) = ra[r];
+            *reinterpret_cast<f32x4*>(a + (lrow + SR * r) * LDS_LD + lc4 * 4) = ra[S][r];
 #pragma unroll
         for (int r = 0; r < BR; ++r)
-            *reinterpret_cast<f32x4*>(b + (lrow + 32 * r) * LDS_LD + lc4 * 4) = rb[r];
+            *reinterpret_cast<f32x4*>(b + (lrow + SR * r) * LDS_LD + lc4 * 4) = rb[S][r];
     };
 
     f32x16 acc[MT][NT];
@@ -143,19 +203,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_chunk(S0{}, 0);
+    load_chunk(S1{}, 1);
+    store_chunk(S0{}, 0);
     __syncthreads();
 
     const int l31 = lane & 31, lhi = lane >> 5;
     const int a_frag = (wm * WTM + l31) * LDS_LD + lhi * 4;
     const int b_frag = (wn * WTN + l31) * LDS_LD + lhi * 4;
 
-    for (int kc = 0; kc < p.nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < p.nk) load_chunk(kc + 1);
-        const float* a = As + buf * BM * LDS_LD + a_frag;
-        const float* b = Bs + buf * BN * LDS_LD + b_frag;
+    // iteration kc (chunk kc is in LDS buffer kc&1; chunk kc+1 is in flight in register set (kc+1)&1)
+    auto iteration = [&](auto par_, int kc) {
+        constexpr int P = decltype(par_)::value;                      // kc & 1
+        load_chunk(std::integral_constant<int, P>{}, kc + 2);
+        const float* a = As + P * BM * LDS_LD + a_frag;
+        const float* b = Bs + P * BN * LDS_LD + b_frag;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 af[MT], bf[NT];
@@ -171,11 +235,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < p.nk) store_chunk(buf ^ 1);
+        store_chunk(std::integral_constant<int, 1 - P>{}, 1 - P);      // (past the end: zeros into a buffer nobody reads)
         __syncthreads();
+    };
+    int kc = 0;
+    for (; kc + 1 < p.nk; kc += 2) {          // both halves unconditional inside the loop: exact vmcnt bookkeeping
+        iteration(S0{}, kc);
+        iteration(S1{}, kc + 1);
     }
+    if (kc < p.nk) iteration(S0{}, kc);
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue
+    if ((p.Cout & 3) == 0 && n0 + wn * WTN + WTN <= p.Cout) {       // wave-uniform; the loop's last __syncthreads freed the LDS
+        epilogue_lds<MT, NT>(acc, p, smem + wid * (WTM * (WTN + 4)), m0 + wm * WTM, n0 + wn * WTN, lane);
+        return;
+    }
+    // straight from the accumulators (the 255-channel head convs)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn * WTN + j * 32 + l31;
@@ -203,10 +278,13 @@ template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, bool k3, bool dual, hipStream_t s) {
     const int mtiles = (p.M + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    if (k3)        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), lds, s, p);
-    else if (dual) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), lds, s, p);
-    else           hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), lds, s, p);
+    const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
+    const size_t lds = pipe > epi ? pipe : epi;
+    const dim3 block(64 * WM * WN);
+    if (k3)        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, lds, s, p);
+    else if (dual) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, lds, s, p);
+    else           hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, lds, s, p);
     YV3_CHECK_LAUNCH();
     return 0;
 }
@@ -235,7 +313,13 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     const int np = d->cout_pad;
     if (np % 128 == 0) {
         const long long blocks128 = ((M + 127) / 128) * (np / 128);
-        if (blocks128 >= 384) { p.ntiles = np / 128; return launch<128, 128, 2, 2>(p, k3, dual, s); }
+        // (tune[0]: kernel-selection override for A/B measurements -- 6 four-wave 128x128, 2 64x64 tiles)
+        if (blocks128 >= 384 && d->tune[0] == 6) { p.ntiles = np / 128; return launch<128, 128, 2, 2>(p, k3, dual, s); }
+        // eight waves (4 x 2 of 32x64) per 128x128 tile, two workgroups per CU: four waves per SIMD hide each other's fragment
+        // reads / barriers better than two (13x13 3x3 layer at bs=64: 80 -> 102 TFLOP/s, whole network +5 %)
+        // 1x1 layers (K <= 1024: 8-32 chunks per tile) run better on 64x64 tiles, four workgroups per CU: 512->256 @26x26 at bs=64
+        // 82 -> 103 TFLOP/s, 256->128 @52x52 95 -> 98 (tune[0] == 7: 128x128 tiles for them too)
+        if (blocks128 >= 384 && d->tune[0] != 2 && (k3 || d->tune[0] == 7)) { p.ntiles = np / 128; return launch<128, 128, 4, 2>(p, k3, dual, s); }
         p.ntiles = np / 64; return launch<64, 64, 2, 2>(p, k3, dual, s);
     }
     if (np % 64 == 0) { p.ntiles = np / 64; return launch<128, 64, 2, 2>(p, k3, dual, s); }
