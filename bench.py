@@ -7,7 +7,7 @@
 A step = one pass of the whole hot path over one batch of synthetic images already resident in HBM, run through
 the PRODUCT entry point `Detector.run_device` (yolo_v3_amd/detect.py: conv0 -> 74 convs with the YOLO decode fused
 into the head convs -> confidence filter -> per-class greedy NMS), then the final [B,cap,7] boxes + counts are
-copied to pinned host memory asynchronously.  For batches >= 16 the Detector runs the convolutions as two sub-batches
+copied to pinned host memory asynchronously.  From ~12 images of 416x416 (8 of 608x608) the Detector runs the convolutions as two sub-batches
 on two concurrent HIP streams ("lanes": same kernels and bits, they fill each other's idle CUs; --lanes 1 disables).  With N > 1 (torch.distributed.run, one rank per GPU) every rank runs
 its shard and each step ends with the RCCL all-gather of the final boxes (yolo_v3_amd/dist.py); --batch is images PER
 GPU (weak scaling, the default), --global-batch fixes the total (strong scaling; BASELINE configs[3] = 256 over 8).
