@@ -123,6 +123,9 @@ __device__ inline void split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
     }
 }
 
+// BF16_OUT (YV3_BF16 mode): same arithmetic (fp32-class products, fp32 accumulate, as conv0_kernel<1> computes them on the
+// vector ALUs), the result rounded to ONE bf16 plane.
+template <bool BF16_OUT>
 __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         u16* __restrict__ y, int H, int W, long long plane_stride,
@@ -196,7 +199,20 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ks], xhi[ks], acc, 0, 0, 0);
         }
         const int gy = r0 + row, gx = c0 + wid * 32 + l31;
-        if (gy < H && gx < W) {
+        if constexpr (BF16_OUT) {
+            if (gy < H && gx < W) {
+                u32x4v qb[2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float t0 = fmaf(acc[2 * q], al[2 * q], be[2 * q]), t1 = fmaf(acc[2 * q + 1], al[2 * q + 1], be[2 * q + 1]);
+                    t0 = __builtin_fmaxf(t0, 0.1f * t0); t1 = __builtin_fmaxf(t1, 0.1f * t1);
+                    qb[q >> 2][q & 3] = (unsigned)yv3_f2bf(t0) | ((unsigned)yv3_f2bf(t1) << 16);
+                }
+                u16* o = y + (((size_t)b * H + gy) * W + gx) * 32 + 8 * lhi;
+                *reinterpret_cast<u32x4v*>(o) = qb[0];
+                *reinterpret_cast<u32x4v*>(o + 16) = qb[1];
+            }
+        } else if (gy < H && gx < W) {
             u32x4v qh[2], ql[2];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -224,10 +240,14 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha, const float* beta,
                          void* y_nhwc, int B, int H, int W, int out_dtype, int* flags, void* stream) {
     if (!x_nchw || !w_tap_major || !alpha || !beta || !y_nhwc || B <= 0 || H <= 0 || W <= 0) return YV3_EINVAL;
-    if (out_dtype == YV3_F32_F16X2) {
+    if (out_dtype == YV3_F32_F16X2 || out_dtype == YV3_BF16) {
         const dim3 g((unsigned)yv3_ceil_div(W, C0_TC), (unsigned)yv3_ceil_div(H, C0_TR), (unsigned)B);
-        hipLaunchKernelGGL(conv0_mfma_kernel, g, dim3(256), 0, (hipStream_t)stream, x_nchw, w_tap_major, alpha, beta,
-                           (u16*)y_nhwc, H, W, (long long)B * H * W * 32, flags);
+        if (out_dtype == YV3_BF16)
+            hipLaunchKernelGGL(conv0_mfma_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, x_nchw, w_tap_major, alpha, beta,
+                               (u16*)y_nhwc, H, W, (long long)B * H * W * 32, flags);
+        else
+            hipLaunchKernelGGL(conv0_mfma_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, x_nchw, w_tap_major, alpha, beta,
+                               (u16*)y_nhwc, H, W, (long long)B * H * W * 32, flags);
         YV3_CHECK_LAUNCH();
         return 0;
     }
@@ -236,8 +256,6 @@ extern "C" int yv3_conv0(const float* x_nchw, const float* w_tap_major, const fl
     const long long ps = (long long)B * H * W * 32;
     if (out_dtype == YV3_F32)
         hipLaunchKernelGGL(conv0_kernel<0>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
-    else if (out_dtype == YV3_BF16)
-        hipLaunchKernelGGL(conv0_kernel<1>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else if (out_dtype == YV3_F32_BF16X3)
         hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, s, x_nchw, w_tap_major, alpha, beta, y_nhwc, H, W, ps);
     else

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
     };
 
     if constexpr (PP) {
-        static_assert(!PP || (NW == 8 && NSTAGE >= 3 && NP == 2), "ping-pong: 8 waves, 3-deep ring, fp16x2 planes");
+        static_assert(!PP || (NW == 8 && NSTAGE >= 3 && NP <= 2), "ping-pong: 8 waves, 3-deep ring, one or two planes");
+        constexpr int NMF = NP == 2 ? 3 : 1;      // MFMAs per (weight tile, pixel tile, k-step)
         const int grp = YV3_PP_GRP(wid);
         // 32x64 wave tiles (128x128 workgroup tile): the compute segment is only 12 MFMAs per k-step, so the second
         // k-step's fragments are fetched under the first k-step's MFMAs; measured +5 % there, -5 % on 64x64 wave tiles
@@ -288,15 +289,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 for (int ks = 0; ks < KS; ++ks) {
                     if (SPLIT && ks == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)                                    // rotate over the accumulators: no back-to-back RAW
+                    for (int t = 0; t < NMF; ++t)                                  // rotate over the accumulators: no back-to-back RAW
 #pragma unroll
                         for (int u = 0; u < NU; ++u) {
                             const int i = u / MT, j = u % MT;
                             const bf16x8v* wf = &frag[ks][i * NP];
                             const bf16x8v* xf = &frag[ks][NT * NP + j * NP];
-                            acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
-                            constexpr int TOT = KS * 3 * NU;                       // one DMA piece after every (TOT / G)-th MFMA
-                            const int mi = (ks * 3 + t) * NU + u;
+                            if constexpr (NP == 2) acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
+                            else acc[i][j] = PlaneOps<1>::mfma(wf[0], xf[0], acc[i][j]);
+                            constexpr int TOT = KS * NMF * NU;                     // one DMA piece after every (TOT / G)-th MFMA
+                            const int mi = (ks * NMF + t) * NU + u;
                             if (more && (mi * G) / TOT != ((mi + 1) * G) / TOT) dma_piece((mi * G) / TOT);
                         }
                 }
@@ -515,6 +517,9 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_
                     num_cu <= YV3_SK_MAX_WG && p.ws_bytes >= yv3_conv_workspace_bytes();
     const dim3 sgrid((unsigned)num_cu);
 #define YV3_LAUNCH(K3_, DUAL_, OF_) do { \
+    if constexpr (NP == 1 && WM * WN == 8 && NSTAGE >= 3) { \
+        if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
+    } \
     if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3) { \
         if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
         if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
@@ -671,7 +676,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
                                          np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, use_pp, s) : \
-                                                   launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s))
+                                                   launch_cfg<1, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, false, s))
     if (npad % 128 == 0) {
         // 256x128 tiles (8 waves, 144 KB LDS; 64x64 per wave) from half a round of tiles upwards, else 128x128 tiles
         // (8 waves of 32x64).  Measured at bs=64: the 13x13 layers have 172 / 344 big tiles (0.7 / 1.3 rounds) and are
@@ -684,6 +689,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int big_min = d->big_tile_min > 0 ? d->big_tile_min : 128;
         const int force = (int)((d->options >> YV3_OPT_TILE_SHIFT) & 0xffu);
         if (np == 2 && force == 3) return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
+        if (np == 1 && force == 3) return launch_cfg<1, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         // short-K 1x1 layers (K <= 512: 8-16 chunks per tile, mostly prologue / epilogue): two independent 4-wave workgroups
         // per CU (128x128 tiles, 2-deep ring) hide each other's IO -- in the network at bs=64 the step gains 0.8 %
@@ -693,6 +699,9 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
             return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         if (force == 1) return YV3_CFG(256, 128, 4, 2, 2);
         if (force == 2) return YV3_CFG(128, 128, 4, 2, 3);
+        // one bf16 plane (YV3_BF16): the same ping-pong loop with one MFMA per unit and a 3-deep ring -- 608x608 bs=16: 2727 -> 3155
+        // images/s on one lane (two 4-wave workgroups per CU instead: 2953)
+        if (np == 1 && use_pp && force == 0 && blocks256 >= big_min) return launch_cfg<1, 256, 128, 4, 2, 3>(p, k3, dual, out_f32, true, s);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
     }
