@@ -234,8 +234,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const Conv
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            // chunk kc+1 (requested 1.5 iterations ago) goes to the other LDS buffer -- free since the last barrier -- in the
+            // MIDDLE of this chunk's MFMAs: by the barrier below the writes have long completed (+1 % over writing at the end)
+            // (past the end: zeros into a buffer nobody reads)
+            if (kk == 1) store_chunk(std::integral_constant<int, 1 - P>{}, 1 - P);
         }
-        store_chunk(std::integral_constant<int, 1 - P>{}, 1 - P);      // (past the end: zeros into a buffer nobody reads)
         __syncthreads();
     };
     int kc = 0;
