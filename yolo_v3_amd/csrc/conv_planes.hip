@@ -699,9 +699,11 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
             return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         if (force == 1) return YV3_CFG(256, 128, 4, 2, 2);
         if (force == 2) return YV3_CFG(128, 128, 4, 2, 3);
-        // one bf16 plane (YV3_BF16): the same ping-pong loop with one MFMA per unit and a 3-deep ring -- 608x608 bs=16: 2727 -> 3155
+        // one bf16 plane (YV3_BF16): the same ping-pong loop with one MFMA per unit -- 608x608 bs=16: 2727 -> 3155
         // images/s on one lane (two 4-wave workgroups per CU instead: 2953)
-        if (np == 1 && use_pp && force == 0 && blocks256 >= big_min) return launch_cfg<1, 256, 128, 4, 2, 3>(p, k3, dual, out_f32, true, s);
+        // (6-deep ring, 147 KB: with 8 MFMAs per chunk and wave a DMA piece needs several chunk times to land; 3-deep 3690, 4-deep
+        // 3830, 6-deep 3870 images/s at 608x608 bs=16)
+        if (np == 1 && use_pp && force == 0 && blocks256 >= big_min) return launch_cfg<1, 256, 128, 4, 2, 6>(p, k3, dual, out_f32, true, s);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
     }
