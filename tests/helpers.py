@@ -6,7 +6,7 @@ TOL = 1e-4          # north-star tolerance: |d| <= 1e-4 * max(1, |ref|), fp32
 
 
 def rel_err(a, ref):
-    a, ref = torch.as_tensor(a).double(), torch.as_tensor(ref).double()
+    a, ref = torch.as_tensor(a).detach().double(), torch.as_tensor(ref).detach().double()
     return ((a - ref).abs() / ref.abs().clamp(min=1.0))
 
 
