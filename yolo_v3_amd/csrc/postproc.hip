@@ -177,7 +177,6 @@ struct NmsWs {
     int* segoff;        // [B][C+1]
     u64* mask;          // [B][max_n][nw]
     u64* pkey;          // [B][max_n] keys partitioned by class (unsorted inside a class)
-    int* cursor;        // [B][C] fill counters of the partition
     int nw;
 };
 
@@ -190,23 +189,13 @@ size_t nms_layout(NmsWs* ws, char* base, int B, int max_n, int C) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
     char* p0 = take(n * 8); char* p1 = take(n * 16); char* p2 = take(n * 4); char* p3 = take(n); char* p4 = take(n);
     char* p5 = take((size_t)B * (C + 1) * 4); char* p6 = take(n * (size_t)nw * 8);
-    char* p7 = take(n * 8); char* p8 = take((size_t)B * C * 4);
+    char* p7 = take(n * 8);
     if (ws) {
         ws->skey = (u64*)p0; ws->sbox = (f32x4*)p1; ws->sconf = (float*)p2; ws->svalid = (unsigned char*)p3;
         ws->keep = (unsigned char*)p4; ws->segoff = (int*)p5; ws->mask = (u64*)p6; ws->nw = nw;
-        ws->pkey = (u64*)p7; ws->cursor = (int*)p8;
+        ws->pkey = (u64*)p7;
     }
     return off;
-}
-
-// segoff[b][c] = exclusive prefix of the class counts; one block per image
-__global__ void segoff_kernel(const int* segcnt, int* segoff, int* cursor, int C) {
-    const int b = blockIdx.x;
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int c = 0; c < C; ++c) { segoff[b * (C + 1) + c] = acc; acc += segcnt[b * C + c]; cursor[b * C + c] = 0; }
-        segoff[b * (C + 1) + C] = acc;
-    }
 }
 
 // Sorting by (class, score desc, row) in two steps: scatter the keys into their class segments (any order inside a segment:
@@ -214,15 +203,29 @@ __global__ void segoff_kernel(const int* segcnt, int* segoff, int* cursor, int C
 // class is the major key, so segoff[cls] + (#smaller keys of the class) is the key's rank among all keys -- the same
 // permutation as rank_kernel's O(n^2) count at sum_c n_c^2 compares (dense scene, 21 k candidates in 37 classes: 13x fewer).
 // An image whose candidate list overflowed (reported to the host as an error) only has to stay inside its buffers.
-__global__ __launch_bounds__(256) void partition_kernel(const u64* __restrict__ keys, int max_cand, const int* __restrict__ counts,
-                                                        NmsWs ws, int C, int max_n) {
-    const int b = blockIdx.y;
+// One workgroup per image: class counts -> LDS, exclusive prefix (-> segoff[b][0..C], used by rank_seg / scan), then the
+// scatter with LDS cursors.
+__global__ __launch_bounds__(256) void segpart_kernel(const u64* __restrict__ keys, int max_cand, const int* __restrict__ counts,
+                                                      const int* __restrict__ segcnt, NmsWs ws, int C, int max_n) {
+    extern __shared__ int sh[];                    // [C + 1] segment offsets, then [C] fill cursors
+    int* off = sh;
+    int* cur = sh + C + 1;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) { off[c + 1] = segcnt[b * C + c]; cur[c] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) { const int v = off[c + 1]; off[c] = acc; acc += v; }
+        off[C] = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c <= C; c += 256) ws.segoff[b * (C + 1) + c] = off[c];
     const int n = min(min(counts[b], max_cand), max_n);
     const u64* kb = keys + (size_t)b * max_cand;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = threadIdx.x; i < n; i += 256) {
         const u64 k = kb[i];
         const int c = min(key_cls(k), C - 1);
-        const int pos = ws.segoff[b * (C + 1) + c] + atomicAdd(&ws.cursor[b * C + c], 1);
+        const int pos = off[c] + atomicAdd(&cur[c], 1);
         if (pos < max_n) ws.pkey[(size_t)b * max_n + pos] = k;
     }
 }
@@ -537,12 +540,14 @@ extern "C" int yv3_postproc_nms(const float* dets, int B, int N, int num_class, 
 
     const int rb = max_n < 256 * 64 ? yv3_ceil_div(max_n, 256) : 64;
     if (use_nms) {
-        hipLaunchKernelGGL(segoff_kernel, dim3(B), dim3(64), 0, s, segcnt, ws.segoff, ws.cursor, num_class);
-        YV3_CHECK_LAUNCH();
-        hipLaunchKernelGGL(partition_kernel, dim3(rb, B), dim3(256), 0, s, keys, max_cand, cand_counts, ws, num_class, max_n);
+        hipLaunchKernelGGL(segpart_kernel, dim3(B), dim3(256), (size_t)(2 * num_class + 1) * sizeof(int), s,
+                           keys, max_cand, cand_counts, segcnt, ws, num_class, max_n);
         YV3_CHECK_LAUNCH();
         const int items = yv3_ceil_div(max_n, 256) + num_class;              // upper bound of (segment, slice) work items per image
-        hipLaunchKernelGGL(rank_seg_kernel, dim3(items < 256 ? items : 256, B), dim3(256), (size_t)(num_class + 1) * sizeof(int), s,
+        // ~2048 workgroups over the batch (each loops over its items): sparse images of a large batch need few of them (bs=64:
+        // 32 per image, 0.12 ms for the NMS stage instead of 0.14 with 256), a dense small batch all of them (bs=8: 256, 0.88 vs 1.01 ms)
+        int rgrid = 2048 / B; rgrid = rgrid < 32 ? 32 : rgrid > 256 ? 256 : rgrid; rgrid = items < rgrid ? items : rgrid;
+        hipLaunchKernelGGL(rank_seg_kernel, dim3(rgrid, B), dim3(256), (size_t)(num_class + 1) * sizeof(int), s,
                            dets, N, num_class, nms_thr, ws, max_n);
     } else {
         hipLaunchKernelGGL(rank_kernel<true>, dim3(rb, B), dim3(256), 0, s, dets, N, num_class, nms_thr, keys, max_cand, cand_counts, ws, max_n);
