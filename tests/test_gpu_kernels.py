@@ -96,9 +96,8 @@ def test_postprocessing_bit_exact_vs_reference_golden(golden_dir):
         assert len(res_cpu) == n and torch.equal(d, keep), "input must not be modified"
 
 
-@pytest.mark.parametrize("B,N,hot,is_eval", [(3, 2000, 700, False), (2, 4000, 1500, False), (2, 1500, 300, True)])
-def test_postprocessing_dense_vs_oracle(B, N, hot, is_eval):
-    """Clustered boxes with heavy suppression (SURVEY App. C-2 recipe), bit-exact vs the oracle."""
+def clustered_detections(B, N, hot):
+    """[B, N, 85] detections: ~hot rows per image pass conf 0.5, centres clustered in five spots, six classes."""
     u = synth.uniform01(900 + N, 1, B * N * 8).reshape(B, N, 8)
     d = np.zeros((B, N, 85), dtype=np.float32)
     centres = np.array([[80, 80], [200, 120], [320, 300], [120, 330], [260, 260]], dtype=np.float32)
@@ -112,7 +111,13 @@ def test_postprocessing_dense_vs_oracle(B, N, hot, is_eval):
     cls = (u[..., 6] * 6).astype(np.int64) * 13
     bi, ri = np.meshgrid(np.arange(B), np.arange(N), indexing="ij")
     d[bi, ri, 5 + cls] = 0.7 + 0.29 * u[..., 7]
-    dt = torch.from_numpy(d)
+    return torch.from_numpy(d)
+
+
+@pytest.mark.parametrize("B,N,hot,is_eval", [(3, 2000, 700, False), (2, 4000, 1500, False), (2, 1500, 300, True)])
+def test_postprocessing_dense_vs_oracle(B, N, hot, is_eval):
+    """Clustered boxes with heavy suppression (SURVEY App. C-2 recipe), bit-exact vs the oracle."""
+    dt = clustered_detections(B, N, hot)
     thr = 0.3 if is_eval else 0.5
     ref = oc.postprocess(dt, 80, thr, 0.4, is_eval, True)
     res = postprocessing(dt.cuda(), 80, thr, 0.4, is_eval, True)
@@ -124,6 +129,31 @@ def test_postprocessing_dense_vs_oracle(B, N, hot, is_eval):
     res = postprocessing(dt.cuda(), 80, thr, 0.4, is_eval, False)
     for r, e in zip(res, ref):
         assert torch.equal(r, e)
+
+
+def test_candidate_buffer_overflow_is_an_error_not_a_crash():
+    """More candidates than the caller-sized buffers hold: the counts say so and to_list raises (no silent truncation); nothing
+    is written out of bounds (the NMS sort partitions by per-class counts that INCLUDE the dropped candidates); the same
+    PostProcessor gives the exact result again on the next, fitting batch."""
+    from yolo_v3_amd.utils import PostProcessor
+    B, N = 3, 4000
+    big, small = clustered_detections(B, N, 1500), clustered_detections(B, N, 40)
+    pp = PostProcessor(B, N, 80, "cuda", max_cand=256, cap=256)
+    pp._workspace(256)                                                            # allocate, then put a guard right behind it
+    guard = torch.full((1 << 22,), 7, dtype=torch.uint8, device="cuda")
+    out, counts = pp.run_sync_free(big.cuda(), 0.5, 0.4, False, True)
+    torch.cuda.synchronize()
+    host = counts.cpu()
+    assert int(host[:B].max()) > 256
+    with pytest.raises(_ffi.Yv3Error, match="overflow"):
+        pp.to_list(out, host)
+    assert int(guard.min()) == 7 and int(guard.max()) == 7
+    out, counts = pp.run_sync_free(small.cuda(), 0.5, 0.4, False, True)
+    got = pp.to_list(out, counts.cpu())
+    want = oc.postprocess(small, 80, 0.5, 0.4, False, True)
+    check_result_convention(got, want)
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
 
 
 def test_nms_properties_at_full_size():
