@@ -9,8 +9,10 @@ torch.cuda.set_device(0)
 stream = synth.weight_stream()
 sd, _ = oc.state_dict_from_stream(stream)
 worst = 0.0
-for sk in (False, True):
+MODE = {"f32h2": _ffi.F32H2, "f32": _ffi.F32, "f32x3": _ffi.F32X3}[os.environ.get("DT", "f32h2")]      # DT: math mode to sweep
+for sk in ((False, True) if MODE == _ffi.F32H2 else (False,)):
     net = load_sw1_net(stream).cuda()
+    net.math_mode = MODE
     net.stream_k = sk
     for (B, H, W) in [(1, 416, 416), (3, 320, 320), (5, 352, 608), (7, 608, 352), (2, 96, 64), (9, 224, 416), (17, 256, 256), (33, 160, 192)]:
         net.img_dim = (W, H)
