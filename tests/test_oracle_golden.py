@@ -164,3 +164,30 @@ def test_eval_mode_at_reference_thresholds_vs_reference(golden_dir):
         assert tuple(r.shape) == tuple(exp.shape)
         assert np.abs(r.numpy() - exp).max() <= 1e-4
         assert np.array_equal(r.numpy()[:, 6], exp[:, 6])
+
+
+def test_cv_resize_restatement_known_answers():
+    """The oracle's restatement of OpenCV's 8-bit fixed-point resize (cv2 is absent here: parity with cv2 itself stays unpinned,
+    DESIGN 6b) must at least reproduce the answers that follow from OpenCV's algorithm without running it: a same-size resize is
+    the identity (fractional offset 0 -> coefficients (0, 2048, 0, 0) / (2048, 0)), a constant image stays constant for every
+    value and scale (the fixed-point coefficient sets sum to 2048 and the rounding shifts are symmetric), and INTER_LINEAR at
+    exactly half size is INTER_AREA's 2x2 mean with +2 >> 2 rounding (resize.cpp re-routes that case)."""
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(oc.cv_resize_cubic_u8(img, 53, 37), img)
+    assert np.array_equal(oc.cv_resize_linear_u8(img, 53, 37), img)
+    for v in (0, 1, 127, 128, 254, 255):
+        c = np.full((20, 30, 3), v, np.uint8)
+        for (w, h) in ((47, 33), (13, 9), (30, 45), (416, 277)):
+            assert np.unique(oc.cv_resize_cubic_u8(c, w, h)).tolist() == [v]
+            assert np.unique(oc.cv_resize_linear_u8(c, w, h)).tolist() == [v]
+    img2 = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8).astype(np.int32)
+    mean = ((img2[0::2, 0::2] + img2[0::2, 1::2] + img2[1::2, 0::2] + img2[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(oc.cv_resize_linear_u8(img2.astype(np.uint8), 30, 20), mean)
+    # letterbox geometry: 602 x 452 -> 416 x 416: a 416 x 312 picture at y = 52 on a 128 background (utils.py:34-56)
+    pic = rng.integers(0, 256, (452, 602, 3), dtype=np.uint8)
+    lb = oc.letterbox_image(pic, (416, 416)).numpy()                       # float32 [3, 416, 416] = uint8 / 255
+    grey = np.float32(128) / np.float32(255)
+    assert lb.shape == (3, 416, 416) and np.all(lb[:, :52] == grey) and np.all(lb[:, 364:] == grey)
+    box = oc.cv_resize_cubic_u8(pic, 416, 312).astype(np.float32) / np.float32(255)
+    assert np.array_equal(lb[:, 52:364], box.transpose(2, 0, 1))
