@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo run of the shard + final-box all-gather (yolo_v3_amd/dist.py)."""
+"""N>1 path on CPU: world_size-2 and -4 gloo runs of the shard + final-box all-gather (yolo_v3_amd/dist.py)."""
 import os
 import socket
+
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -36,11 +38,13 @@ def _worker(rank, world, port, q):
     lst = ydist.boxes_to_list(ab, ac)
     ok = ok and len(lst) == B * world and lst[0].shape == (0,) and lst[1].shape == (1, 7)
     # the sharded-detect plumbing around the single-GPU pipeline (dist.detect_sharded): UNEVEN split of a global
-    # batch of 5 over 2 ranks, padded shards, one all-gather, padding dropped, reference result convention
+    # batch of 5 over the ranks, padded shards, one all-gather, padding dropped, reference result convention
     Bg, cap2 = 5, 4
     imgs = torch.arange(Bg, dtype=torch.float32).view(Bg, 1, 1, 1).expand(Bg, 3, 2, 2).contiguous()     # image id in every pixel
     x, b_pad, spans = ydist.take_shard(imgs, rank, world)
-    ok = ok and b_pad == 3 and spans == [(0, 3), (3, 5)] and x.shape[0] == 3
+    want_spans = [ydist.shard_range(Bg, r_, world) for r_ in range(world)]      # world 2: [(0, 3), (3, 5)]; world 4: 2, 1, 1, 1 images
+    want_pad = max(h_ - l_ for l_, h_ in want_spans)
+    ok = ok and b_pad == want_pad and [tuple(sp) for sp in spans] == want_spans and x.shape[0] == want_pad
     ids = x[:, 0, 0, 0].to(torch.int64)                                 # what this rank "detects": image g keeps g % 3 boxes
     bx = torch.zeros(b_pad, cap2, 7)
     meta = torch.zeros(b_pad, 3, dtype=torch.int32)
@@ -58,27 +62,31 @@ def _worker(rank, world, port, q):
         ok = ok and (n == 0 or bool((res[g][:, 0] == float(g)).all()))
     # nothing anywhere -> the [] sentinel; a status bit set on ONE rank is seen by all
     meta0 = torch.zeros(b_pad, 3, dtype=torch.int32)
-    meta0[:, 2] = rank                                                  # rank 1 reports status 1
+    meta0[:, 2] = rank                                                  # rank r reports status r: everyone must see the OR
     gb, gm = ydist.gather_boxes(torch.zeros(b_pad, cap2, 7), meta0.view(-1))
     res0, status0 = ydist.assemble_global(gb, gm, spans, b_pad, 10, cap2)
-    ok = ok and res0 == [] and status0 == 1
+    want_status = 0
+    for r_ in range(world):
+        want_status |= r_
+    ok = ok and res0 == [] and status0 == want_status
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_boxes_world2_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_boxes_gloo(world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_single_process_is_identity():
