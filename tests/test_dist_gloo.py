@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 and -4 gloo runs of the shard + final-box all-gather (yolo_v3_amd/dist.py)."""
+"""N>1 path on CPU: world_size-2, -4 and -8 gloo runs (8: three ranks own NO image of the 5-image batch) of the shard + final-box all-gather (yolo_v3_amd/dist.py)."""
 import os
 import socket
 
@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     Bg, cap2 = 5, 4
     imgs = torch.arange(Bg, dtype=torch.float32).view(Bg, 1, 1, 1).expand(Bg, 3, 2, 2).contiguous()     # image id in every pixel
     x, b_pad, spans = ydist.take_shard(imgs, rank, world)
-    want_spans = [ydist.shard_range(Bg, r_, world) for r_ in range(world)]      # world 2: [(0, 3), (3, 5)]; world 4: 2, 1, 1, 1 images
+    want_spans = [ydist.shard_range(Bg, r_, world) for r_ in range(world)]      # world 2: [(0, 3), (3, 5)]; world 4: 2, 1, 1, 1 images; world 8: five ranks with one image, three with none
     want_pad = max(h_ - l_ for l_, h_ in want_spans)
     ok = ok and b_pad == want_pad and [tuple(sp) for sp in spans] == want_spans and x.shape[0] == want_pad
     ids = x[:, 0, 0, 0].to(torch.int64)                                 # what this rank "detects": image g keeps g % 3 boxes
@@ -74,7 +74,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_gather_boxes_gloo(world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
