@@ -33,7 +33,7 @@ def main():
                "conv_planes_kernel (other modes)" if "conv_planes" in n else
                "conv_front" if "front" in n else "conv_res64" if "conv_res64" in n else "conv_1x1" if "conv1x1" in n else
                "conv_igemm_f32_kernel" if "conv_igemm" in n else "conv0" if "conv0" in n else
-               "postproc" if any(k in n for k in ("filter_kernel", "rank_kernel", "mask_kernel", "scan_kernel", "compact_kernel", "zero_kernel")) else None)
+               "postproc" if any(k in n for k in ("filter_kernel", "rank_kernel", "rank_seg_kernel", "segpart_kernel", "mask_kernel", "scan_kernel", "compact_kernel", "zero_kernel")) else None)
         if key is None or di not in dur:
             continue
         f = fam.setdefault(key, {"dispatches": 0, "wall_ns": 0, "mfma_busy": 0.0, "sq_busy": 0.0, "gui": 0.0})
