@@ -5,37 +5,49 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64 | --global-batch G] [--size 416] [--dtype f32h2]
 
 A step = one pass of the whole hot path over one batch of synthetic images already resident in HBM, run through
-the PRODUCT entry point `Detector.run_device` (yolo_v3_amd/detect.py: conv0 -> 74 convs with the YOLO decode fused
-into the head convs -> confidence filter -> per-class greedy NMS), then the final [B,cap,7] boxes + counts are
-copied to pinned host memory asynchronously.  From ~12 images of 416x416 (8 of 608x608) the Detector runs the convolutions as two sub-batches
-on two concurrent HIP streams ("lanes": same kernels and bits, they fill each other's idle CUs; --lanes 1 disables).  With N > 1 (torch.distributed.run, one rank per GPU) every rank runs
-its shard and each step ends with the RCCL all-gather of the final boxes (yolo_v3_amd/dist.py); --batch is images PER
-GPU (weak scaling, the default), --global-batch fixes the total (strong scaling; BASELINE configs[3] = 256 over 8).
-Rank 0 prints ONE JSON line.
+the PRODUCT entry points: `Detector.run_device` at N = 1 (yolo_v3_amd/detect.py: conv0 -> 74 convs with the YOLO decode
+fused into the head convs -> confidence filter -> per-class greedy NMS) and `ShardedDetector.run_device` at N > 1
+(yolo_v3_amd/dist.py: the same per-rank pipeline + the ONE all-gather of the [B_local, cap+1, 7] payload -- boxes plus a
+row with candidate / kept counts and the kernels' status word -- over RCCL; it is what `detect_sharded` runs), then
+the result is copied to pinned host memory asynchronously.  The list conversion (`assemble`, the path's one host sync)
+is outside the timed region and runs once after it (it also checks the status word).
+
+Launch: `python bench.py --gpus N` with N > 1 and no torchrun environment RE-LAUNCHES ITSELF under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU) and
+fails loudly when fewer than N GPUs are visible (YV3_DIST_BACKEND=gloo: rehearsal mode, ranks may share a GPU and gloo
+carries the gather); launched under torchrun it requires WORLD_SIZE == --gpus.  `--dry-run` exercises launcher,
+rendezvous, the product's pack -> gather -> assemble composition and the JSON line on CPU tensors (no GPU, no kernels;
+tests/test_bench_launcher.py).
+
+From ~12 images of 416x416 (8 of 608x608) the Detector runs the batch as two sub-batches on two concurrent HIP streams
+("lanes": same kernels and bits, each lane runs its own convolutions AND its own filter / NMS, so they fill each
+other's idle CUs; --lanes 1 disables; under N > 1 the automatic lane count is MIN-reduced over the ranks).  --batch is
+images PER GPU (weak scaling, the default), --global-batch fixes the total (strong scaling; BASELINE configs[3] = 256
+over 8).  Rank 0 prints ONE JSON line.
 
 `roofline` is for the dominant kernel family, the implicit-GEMM convolution (conv_planes_kernel<2,...> in the default
-fp16x2-plane mode: 71 launches per step behind the two fused front kernels -- first two layers, first residual block -- and 74 in the other modes): algorithmic FLOPs
+fp16x2-plane mode: 71 launches per step behind the two fused front kernels, 74 in the other modes): algorithmic FLOPs
 (2*MAC) of those convs for the batch divided by the duration of their launch sequence, measured with HIP events on the
-launch stream in every timed step (`all_75_convs_frac`: all 75 convs over front + convs time).  In the
-default mode each fp32 product costs 3 fp16 MFMAs, so the peak for ALGORITHMIC FLOP/s is 2500/3 TFLOP/s and `frac`
-is the utilisation of the 16-bit matrix pipe.  It is measured with ONE lane (the kernels alone on the chip: with two
-concurrent lanes a kernel's duration includes the time it shares the chip, and rocprofv3's per-kernel durations sum to
-~2x the wall time); `roofline.two_lanes_conv_section` is the rate of the conv section as the timed step runs it (all 75
-convs' FLOPs over the fork -> join wall time).  `stages_ms` is the per-stage split of the timed step from HIP events.
+launch stream in every timed step.  In the default mode each fp32 product costs 3 fp16 MFMAs, so the peak for
+ALGORITHMIC FLOP/s is 2500/3 TFLOP/s and `frac` is the utilisation of the 16-bit matrix pipe.  It is measured with ONE
+lane (the kernels alone on the chip); `roofline.two_lanes_section` is the rate of the concurrent section as the timed
+step runs it (all 75 convs' FLOPs over the fork -> join wall time, which also contains the lanes' filter + NMS).
 
-Extra objects on the same line (rank 0, N = 1; --no-extras skips them):
+Extra objects on the same line (--no-extras skips them):
   cpu_baseline   the CPU oracle (oracle/oracle_cpu.py: the reference path restated in torch fp32 CPU ops) timed on this
-                 box's host cores on a bounded sample;
-  boxes_delta    "NMS boxes delta vs ref": the HIP path's final boxes vs the oracle's on that same sample
-                 (oracle/boxdelta.py: max rel error of coords / scores over matched boxes, class / count equality,
-                 unmatched fraction);
-  modes          the other fp32-class math modes on the headline workload (f32x3, exact f32);
-  configs        BASELINE.json configs 1 / 2 / 4 (by list index) and eval mode at the reference's 0.005 / 0.45.
+                 box's host cores on bounded samples (416x416 bs=8, 608x608 bs=4, the dog image
+                 bs=1; forward / decode / post-processing split);
+  boxes_delta    "NMS boxes delta vs ref": the HIP path's final boxes vs the oracle's on the 416x416 sample;
+  modes          the other math modes on the headline workload (f32x3, exact f32, bf16);
+  configs        BASELINE.json configs by list index: "0" dog image bs=1 (GPU latency eager + HIP graph, CPU ms), "1",
+                 "2", "3" (416x416, 256 images in total over the N GPUs of this run), "4", and eval mode at the reference's
+                 0.005 / 0.45 ("eval": `Detector`; "eval_predict_and_process": the reference-shaped entry).
 """
 import argparse
 import glob
 import json
 import os
+import socket
 import sys
 import time
 
@@ -69,48 +81,107 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(stream, size, conf, nms, n_img=8):
-    """Oracle (CPU restatement of the reference path) on the host cores: forward + post-processing.
-    Returns (cpu_baseline object, the sample images, the oracle's boxes for them)."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(n, dry):
+    """`python bench.py --gpus N` without a torchrun environment: become N ranks (one per GPU)."""
+    if not dry and os.environ.get("YV3_DIST_BACKEND") != "gloo":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d needs %d visible GPUs (one rank per GPU over RCCL), found %d.  "
+                             "(YV3_DIST_BACKEND=gloo rehearses the N-rank path on fewer GPUs: ranks then share devices "
+                             "and gloo carries the gather -- functional check only, not a measurement.)\n" % (n, n, have))
+            sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _best(fn, reps=2):
+    fn()                                                  # warm-up
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, out
+
+
+def cpu_baseline(stream, conf, nms, dog=None):
+    """Oracle (CPU restatement of the reference path) on the host cores, as BASELINE.md section 4 plans it: 416x416 bs=8,
+    608x608 bs=4 and the dog image bs=1; conv trunk / decode / post-processing timed separately (best of 2 after a
+    warm-up each).  Returns (cpu_baseline object, the 416 sample, the oracle's boxes for it)."""
     from oracle import oracle_cpu as oc
     from yolo_v3_amd import synth
     cores = usable_cores()
     torch.set_num_threads(cores)
     sd, _ = oc.state_dict_from_stream(stream)
-    x = torch.from_numpy(synth.images(n_img, size, 1))
-    best, boxes = None, None
-    t_all = time.perf_counter()
-    for it in range(3):                                   # 1 warm-up + 2 timed, stop early if slow
-        t0 = time.perf_counter()
-        boxes = oc.detect(sd, x, 80, conf, nms)
-        dt = time.perf_counter() - t0
-        if it > 0:
-            best = dt if best is None else min(best, dt)
-        if time.perf_counter() - t_all > 25 and best is not None:
-            break
-    obj = {"value": round(n_img / best, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-           "sample": "%d images %dx%d, forward+decode+NMS, torch fp32 CPU ops, best of %d after 1 warm-up"
-                     % (n_img, size, size, max(1, it))}
-    return obj, x, boxes
+    samples = {}
+    keep = None
+
+    def run(tag, x):
+        img_dim = (x.shape[3], x.shape[2])
+        with torch.no_grad():
+            t_trunk, logits = _best(lambda: oc.head_logits(sd, x))
+            t_dec, dets = _best(lambda: torch.cat([oc.decode(l, oc.DEFAULT_ANCHORS, m, img_dim, 80)
+                                                   for l, m in zip(logits, ((6, 7, 8), (3, 4, 5), (0, 1, 2)))], 1))
+            t_pp, boxes = _best(lambda: oc.postprocess(dets.clone(), 80, conf, nms))
+        n = x.shape[0]
+        tot = t_trunk + t_dec + t_pp
+        samples[tag] = {"images": n, "ms_per_img": {"conv_trunk": round(t_trunk / n * 1e3, 2), "decode": round(t_dec / n * 1e3, 3),
+                                                    "postprocessing": round(t_pp / n * 1e3, 3), "total": round(tot / n * 1e3, 2)},
+                        "images_per_sec": round(n / tot, 3)}
+        return boxes
+
+    x416 = torch.from_numpy(synth.images(8, 416, 1))
+    keep = run("416x416_bs8", x416)
+    run("608x608_bs4", torch.from_numpy(synth.images(4, 608, 2)))
+    if dog is not None:
+        run("dog_416x416_bs1", dog)
+    obj = {"value": samples["416x416_bs8"]["images_per_sec"], "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "oracle/oracle_cpu.py (torch fp32 CPU ops, %d threads), SW-1 weights: 8 images 416x416 (value), 4 images 608x608, "
+                     "the letterboxed dog image; conv trunk, decode and post-processing timed separately, best of 2 after 1 warm-up" % cores,
+           "samples": samples}
+    return obj, x416, keep
 
 
+# ------------------------------------------------------------------------------------------------ workloads
 class Workload:
-    """One (weights, batch, size, mode, thresholds) configuration measured through Detector.run_device."""
+    """One (weights, batch, size, mode, thresholds) configuration measured through the product entry:
+    `Detector.run_device` (world 1) / `ShardedDetector.run_device` (world > 1: + the one all-gather)."""
 
     def __init__(self, net, x, mode, conf, nms, is_eval=False, world=1, cap_host=512, max_cand=None, lanes=None):
         from yolo_v3_amd import Detector, _ffi
+        from yolo_v3_amd import dist as ydist
         codes = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3, "f32h2": _ffi.F32H2}
         self.x, self.world, self.mode = x, world, mode
         B, _, H, W = x.shape
         self.B, self.size = B, H
-        self.det = Detector(net, B, H, W, conf, nms, is_eval=is_eval, dtype=codes[mode], max_cand=max_cand, lanes=lanes)
-        self.cap_host = min(self.det.pp.cap, cap_host)
-        self.host_boxes = torch.empty((B * world, self.cap_host, 7), dtype=torch.float32).pin_memory()
-        self.host_counts = torch.empty((2 * B * world,), dtype=torch.int32).pin_memory()
+        if world > 1:
+            assert not is_eval
+            self.sd = ydist.ShardedDetector(net, B, H, W, conf, nms, True, cap=cap_host, dtype=codes[mode], lanes=lanes)
+            self.det = self.sd.det
+            self.host = torch.empty((B * world, self.sd.cap + 1, 7), dtype=torch.float32).pin_memory()
+        else:
+            self.sd = None
+            self.det = Detector(net, B, H, W, conf, nms, is_eval=is_eval, dtype=codes[mode], max_cand=max_cand, lanes=lanes)
+            self.cap_host = min(self.det.cap, cap_host)
+            self.host = torch.empty((B, self.cap_host, 7), dtype=torch.float32).pin_memory()
+        self.host_counts = torch.empty((2 * B,), dtype=torch.int32).pin_memory()
         self.events = []
+        self.gathered = None
 
     def step(self, timed):
-        from yolo_v3_amd import dist as ydist
         marks = {}
 
         def mark(name):
@@ -118,14 +189,13 @@ class Workload:
             ev.record()                                   # on torch's current stream == the kernels' launch stream
             marks[name] = ev
 
-        boxes, counts = self.det.run_device(self.x, mark if timed else None)     # product code: conv0 ... NMS
-        boxes = boxes[:, :self.cap_host]
-        if self.world > 1:
-            boxes, counts = ydist.gather_boxes(boxes.contiguous(), counts)
-            if timed:
-                mark("gather")
-        self.host_boxes.copy_(boxes, non_blocking=True)
-        self.host_counts.copy_(counts, non_blocking=True)
+        if self.sd is not None:
+            self.gathered = self.sd.run_device(self.x, mark if timed else None)      # product code: conv0 ... NMS, pack, all-gather
+            self.host.copy_(self.gathered, non_blocking=True)
+        else:
+            boxes, counts = self.det.run_device(self.x, mark if timed else None)     # product code: conv0 ... NMS
+            self.host.copy_(boxes[:, :self.cap_host], non_blocking=True)
+            self.host_counts.copy_(counts, non_blocking=True)
         if timed:
             mark("d2h")
             self.events.append(marks)
@@ -145,15 +215,28 @@ class Workload:
             fence()
             elapsed = time.perf_counter() - t0
         if self.world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.x.device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.x.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        # status word of the default mode (fp16 saturation) -- product code checks it in Detector.__call__
-        self.det.engine.raise_if_overflowed(self.det.plan, int(self.det.plan.flags.item()))
         return elapsed
 
+    def finish(self, rank=0):
+        """Outside the timed region: what the product entry does with the result (list conversion = the one host
+        sync; raises on a kernel status bit of ANY rank).  Returns (candidates, kept) of the first images."""
+        if self.sd is not None:
+            from yolo_v3_amd import dist as ydist
+            spans = ydist.shard_plan(self.B, self.world, local_shard=True)[1]
+            res = self.sd.assemble(self.gathered, spans)
+            _, meta = ydist.unpack_payload(self.gathered)
+            meta = meta.cpu()
+            assert res == [] or len(res) == self.B * self.world
+            return meta[:4, 0].tolist(), meta[:4, 1].tolist()
+        self.det.engine.raise_if_overflowed(self.det.plan, int(self.det.plan.flags.item()))
+        c = self.host_counts
+        return c[:4].tolist(), c[self.B:self.B + 4].tolist()
+
     def stages_ms(self):
-        order = ["start"] + [s for s in STAGES] + (["gather"] if self.world > 1 else []) + ["d2h"]
+        order = ["start"] + [s for s in STAGES] + (["gather"] if self.sd is not None else []) + ["d2h"]
         out = {}
         for prev, cur in zip(order, order[1:]):
             out[cur] = round(sum(m[prev].elapsed_time(m[cur]) for m in self.events) / len(self.events), 4)
@@ -161,15 +244,16 @@ class Workload:
 
     def flops(self):
         """(2*MAC of all 75 convs, 2*MAC of the launches timed as the 'convs' stage, number of those launches).
-        The 'conv0' stage is the network's front: feature.mlist.0 alone, or -- fp16-plane mode, csrc/conv_front.hip -- the
-        first TWO layers in one launch; the 'convs' stage is the remaining 74 / 73 implicit-GEMM launches."""
+        One lane: the 'conv0' stage is the network's front (feature.mlist.0 alone, or -- fp16-plane mode -- the two fused
+        front launches) and 'convs' the remaining implicit-GEMM launches.  Two lanes: 'convs' is the whole concurrent
+        section (every conv launch of every lane, plus the lanes' filter + NMS)."""
         from yolo_v3_amd import arch
         specs = arch.conv_specs()
         hw = arch.conv_output_hw(self.size)
         macs = [h * w * sp.cout * sp.cin * sp.k * sp.k for sp, (h, w) in zip(specs, hw)]
         plan = self.det.plan
         first = 1 + plan.first_desc
-        if self.det.lanes > 1:                              # lanes: the 'convs' stage covers every conv launch of every lane
+        if self.det.lanes > 1:
             return 2.0 * sum(macs) * self.B, 2.0 * sum(macs) * self.B, sum(1 + (p.first_desc > 0) + (p.first_desc > 1) + p.n_desc - p.first_desc
                                                                          for p in self.det.lane_plans)
         return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, plan.n_desc - plan.first_desc
@@ -179,12 +263,15 @@ class Workload:
         fa, fi, nl = self.flops()
         ach = fi / (st["convs"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[self.mode]
+        lanes = self.det.lanes
         return {"dtype": DTYPE_NAME[self.mode], "value": round(self.B * self.world * steps / elapsed, 2), "unit": "images/sec",
                 "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_img": round(elapsed / steps * 1e3 / (self.B * self.world), 5),
-                "stages_ms": st,
-                "lanes": self.det.lanes,
-                "roofline": {"bound": "mfma", "kernel": ("%s (%d launches/step)" % (KERNEL_NAME[self.mode], nl)) if self.det.lanes == 1 else
-                             ("all conv launches of %d concurrent lanes (%d/step): FLOPs over the wall time of the conv section" % (self.det.lanes, nl)),
+                "stages_ms": st, "lanes": lanes,
+                "stages_note": ("one lane: consecutive stages on the launch stream" if lanes == 1 else
+                                "%d lanes: 'convs' = fork -> join of the concurrent section (each lane: front, convs, filter, NMS on its own stream); "
+                                "'decode' / 'filter' / 'nms' are inside it" % lanes),
+                "roofline": {"bound": "mfma", "kernel": ("%s (%d launches/step)" % (KERNEL_NAME[self.mode], nl)) if lanes == 1 else
+                             ("all conv launches of %d concurrent lanes (%d/step): FLOPs over the wall time of the concurrent section (incl. the lanes' filter + NMS)" % (lanes, nl)),
                              "achieved": round(ach, 2),
                              "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches": nl,
                              "all_75_convs_frac": round(fa / ((st["conv0"] + st["convs"]) * 1e-3) / 1e12 / peak, 4)}}
@@ -197,10 +284,68 @@ def make_net(stream, size, dev):
     return net.to(dev)
 
 
-def scenes(B, size, seed, dev, distinct=16):
+def scenes(B, size, seed, dev, distinct=64):
+    """B synthetic scenes; up to `distinct` different ones (default 64: every image of the headline batch differs -- the
+    conv kernels' speed is data-dependent on this power-limited chip), tiled beyond that."""
     from yolo_v3_amd import synth
-    base = synth.images(min(B, distinct), size, seed)                     # `distinct` different scenes, tiled
+    base = synth.images(min(B, distinct), size, seed)
     return torch.from_numpy(base).to(dev).repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous()
+
+
+def attach_traffic(roof, dtype, size, B, n_desc):
+    """HBM traffic of the dominant kernel family: FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes (they
+    cannot be sampled from inside this process); the committed summary of those passes over THIS workload is attached
+    and labelled with its source run (tools/traffic_summary.py -> profiles/*_traffic_<dtype>_<size>_bs<B>.json)."""
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic_%s_%d_bs%d.json" % (dtype, size, B))))
+    roof["traffic"] = None
+    if not cands:
+        return
+    fam = json.load(open(cands[-1])).get(KERNEL_NAME[dtype].split("<")[0])
+    if fam:
+        roof["traffic"] = round(fam["hbm_bytes_per_step_fetch_x2"] / n_desc)
+        roof["traffic_source"] = os.path.basename(cands[-1])
+        roof["traffic_note"] = ("HBM bytes per launch (avg of %d launches/step) = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate "
+                                "rocprofv3 --pmc passes of this workload, NOT measured in this run; FETCH_SIZE doubled per the "
+                                "gfx950 calibration in MI355X_MICROARCH.md" % n_desc)
+
+
+def dry_run(args, rank, world):
+    """Launcher / rendezvous / collective / JSON-line rehearsal on CPU tensors: every rank builds a synthetic payload
+    with the PRODUCT's pack function, runs the product's single all-gather K times (barrier + max-over-ranks timing as
+    the real run) and assembles the global result.  No GPU, no kernels, no throughput claim."""
+    from yolo_v3_amd import dist as ydist
+    B, cap = 4, 8
+    lo, _ = ydist.shard_range(B * world, rank, world)
+    boxes = torch.zeros(B, cap, 7)
+    kept = torch.tensor([(lo + i) % 3 for i in range(B)], dtype=torch.int32)
+    for i in range(B):
+        boxes[i, :int(kept[i]), 0] = float(lo + i)
+    payload = ydist.pack_payload(boxes, kept, kept, torch.zeros(1, dtype=torch.int32))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = ydist.gather_payload(payload)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    spans = ydist.shard_plan(B, world, local_shard=True)[1]
+    res, status = ydist.assemble_global(gathered, spans, B, max_cand=cap)
+    ok = status == 0 and len(res) == B * world and all((r.shape[0] if r.numel() else 0) == g % 3 for g, r in enumerate(res))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: launcher + pack/gather/assemble on CPU tensors (no kernels)", "value": None, "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "n/a", "data": "dry-run",
+                          "config": {"workload": "dry run", "global_batch": B * world, "parallelism": "dp%d" % world,
+                                     "backend": dist.get_backend() if world > 1 else None}, "ok": bool(ok)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
 
 
 def main():
@@ -219,22 +364,37 @@ def main():
                     "2 when it measures a gain on this GPU, else 1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra modes / configs measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + collective rehearsal on CPU tensors (no GPU needed)")
     ap.add_argument("--weights", default="sw1", choices=["sw1", "dense", "eval"],
                     help="sw1: ~50-150 candidates/img; dense: ~1e4 rows/img pass conf (BASELINE configs[4]); eval: SW-eval")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        relaunch_under_torchrun(args.gpus, args.dry_run)              # does not return
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (`python bench.py --gpus N` does it itself, or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)\n" % (args.gpus, env_world))
+        sys.exit(2)
+
     from yolo_v3_amd import synth, dist as ydist
 
-    rank, local, world = ydist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
+    rank, local, world = ydist.init_from_env(backend="gloo" if args.dry_run else None)
+    if args.dry_run:
+        dry_run(args, rank, world)
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py needs the MI355X (there is no CPU path)\n")
+        sys.exit(2)
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     strong = args.global_batch > 0
     if strong:
-        assert args.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"
+        if args.global_batch % world:
+            sys.stderr.write("--global-batch must be a multiple of the number of GPUs\n")
+            sys.exit(2)
         B = args.global_batch // world
     else:
         B = args.batch
@@ -246,20 +406,19 @@ def main():
 
     main_w = Workload(net, x, args.dtype, args.conf, args.nms, world=world, lanes=args.lanes or None)
     elapsed = main_w.run(args.steps, args.warmup)
+    cand4, kept4 = main_w.finish(rank)
     if rank == 0 and os.environ.get("YV3_DUMP_PLAN"):               # for tools/trace_layers.py: conv spec index of every launch
         p_ = main_w.det.plan
         json.dump({"first_desc": p_.first_desc, "desc_spec": p_.desc_spec}, open(os.environ["YV3_DUMP_PLAN"], "w"))
     head = main_w.summary(elapsed, args.steps)
-    kept4 = main_w.host_counts[B:B + 4].tolist()                       # rank 0's shard: [0:B] candidates, [B:2B] kept
 
     # The roofline of the dominant KERNEL is measured with the kernels running alone (one lane): with two concurrent lanes a
     # kernel's duration includes the time it shares the chip with the other lane's kernels (rocprofv3 then shows per-kernel
-    # durations that sum to ~2x the wall time).  The two-lane conv-section rate (FLOPs over wall) is reported next to it.
+    # durations that sum to ~2x the wall time).  The two-lane section rate (FLOPs over wall) is reported next to it.
     lanes_used = main_w.det.lanes
     roof_w, head1 = main_w, head
     if lanes_used > 1 and rank == 0:
-        # rank-local (world=1: no collective inside) -- whether a rank runs two lanes is ITS calibration's decision, so a pass
-        # with barriers here could leave the ranks waiting for each other
+        # rank-local (world=1: no collective inside), so no rank waits for another here
         roof_w = Workload(net, x, args.dtype, args.conf, args.nms, world=1, lanes=1)
         e1 = roof_w.run(min(args.steps, 10), 3)
         head1 = roof_w.summary(e1, min(args.steps, 10))
@@ -273,12 +432,15 @@ def main():
             "ms_per_step": head["ms_per_step"], "ms_per_img": head["ms_per_img"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.dtype], "data": "synthetic",
-            "config": {"workload": "%dx%d bs=%d per GPU, synthetic scenes, %s synthetic weights, conf=%.2f nms=%.2f"
-                                   % (args.size, args.size, B, {"sw1": "SW-1", "dense": "SW-dense", "eval": "SW-eval"}[args.weights],
+            "config": {"workload": "%dx%d bs=%d per GPU, %d distinct synthetic scenes per GPU, %s synthetic weights, conf=%.2f nms=%.2f"
+                                   % (args.size, args.size, B, min(B, 64), {"sw1": "SW-1", "dense": "SW-dense", "eval": "SW-eval"}[args.weights],
                                       args.conf, args.nms),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "entry": "Detector.run_device",
-                       "boxes_kept_first_images": kept4},
-            "stages_ms": head["stages_ms"], "lanes": lanes_used,
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "entry": "ShardedDetector.run_device (= detect_sharded without the list conversion)" if world > 1 else "Detector.run_device",
+                       "collective": ("1 x all_gather_into_tensor of [%d, %d, 7] fp32 per rank, backend %s" % (B, main_w.sd.cap + 1, dist.get_backend()))
+                       if world > 1 else None,
+                       "candidates_first_images": cand4, "boxes_kept_first_images": kept4},
+            "stages_ms": head["stages_ms"], "stages_note": head["stages_note"], "lanes": lanes_used,
             "roofline": dict(head1["roofline"], traffic=None,
                              conv_ms_per_step=st["convs"], avg_launch_ms=round(st["convs"] / n_desc, 5),
                              flop_per_launch_avg=fi / n_desc,
@@ -287,31 +449,39 @@ def main():
         if lanes_used > 1:
             out["roofline"]["measured_with"] = ("lanes=1 (%.2f images/s, %.3f ms/step): the kernels run alone, so HIP-event and rocprofv3 per-kernel durations "
                                                 "mean what they say; the timed step above runs %d concurrent lanes" % (head1["value"], head1["ms_per_step"], lanes_used))
-            out["roofline"]["two_lanes_conv_section"] = {k: head["roofline"][k] for k in ("kernel", "achieved", "frac", "launches")}
+            out["roofline"]["two_lanes_section"] = {k: head["roofline"][k] for k in ("kernel", "achieved", "frac", "launches")}
             out["lanes_calibration_ms"] = getattr(main_w.det, "lane_calibration", None)
-        # HBM traffic of the dominant kernel family: FETCH_SIZE / WRITE_SIZE need their own rocprofv3 --pmc passes
-        # (they cannot be sampled from inside this process); the committed summary of those passes over THIS workload
-        # is attached and labelled with its source run (tools/traffic_summary.py -> profiles/*_traffic_*.json).
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic_%s_%d_bs%d.json" % (args.dtype, args.size, B))))
-        if cands:
-            fam = json.load(open(cands[-1])).get(KERNEL_NAME[args.dtype].split("<")[0])
-            if fam:
-                out["roofline"]["traffic"] = round(fam["hbm_bytes_per_step_fetch_x2"] / n_desc)
-                out["roofline"]["traffic_source"] = os.path.basename(cands[-1])
-                out["roofline"]["traffic_note"] = ("HBM bytes per launch (avg of %d launches/step) = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate "
-                                                   "rocprofv3 --pmc passes of this workload, NOT measured in this run; FETCH_SIZE doubled per the "
-                                                   "gfx950 calibration in MI355X_MICROARCH.md" % n_desc)
+        attach_traffic(out["roofline"], args.dtype, args.size, B, n_desc)
         if args.dtype in ("f32x3", "f32h2"):
             nm = {"f32x3": 6, "f32h2": 3}[args.dtype]
             ach = out["roofline"]["achieved"]
             out["roofline"]["note"] = ("achieved = algorithmic fp32 FLOP/s; peak = 2500 TFLOP/s dense 16-bit MFMA / %d MFMAs per fp32 "
                                        "product, so frac = matrix-pipe utilisation (%.0f TFLOP/s executed)" % (nm, nm * ach))
             out["roofline"]["frac_vs_fp32_mfma_peak"] = round(ach / PEAK_TFLOPS["f32"], 4)
+    del roof_w
+
+    sub_steps, sub_warm = 10, 3
+    if not args.no_extras:
+        # ---- BASELINE configs[3]: 416x416, 256 images in total, sharded over the GPUs of THIS run (every rank takes part)
+        if 256 % world == 0 and not (strong and args.global_batch == 256 and args.size == 416):
+            b3 = 256 // world
+            lo3, _ = ydist.shard_range(256, rank, world)
+            net416 = net if args.size == 416 and args.weights == "sw1" else make_net(synth.weight_stream(), 416, dev)
+            w3 = Workload(net416, scenes(b3, 416, 3000 + lo3, dev), args.dtype, 0.5, 0.4, world=world, lanes=args.lanes or None)
+            e3 = w3.run(sub_steps, sub_warm)
+            c3, k3 = w3.finish(rank)
+            if rank == 0:
+                s3 = w3.summary(e3, sub_steps)
+                s3["workload"] = ("BASELINE configs[3]: 416x416, global batch 256 sharded over %d GPU(s) (%d per GPU), RCCL box gather; "
+                                  "the config names 8 GPUs" % (world, b3))
+                s3["kept_per_img_first4"], s3["candidates_per_img_first4"] = k3, c3
+                out.setdefault("configs", {})["3"] = s3
+            del w3, net416
+            torch.cuda.empty_cache()
 
     extras = world == 1 and not args.no_extras and rank == 0
     if extras:
-        sub_steps, sub_warm = 10, 3
-        # ---- the other fp32-class modes on the headline workload (driver-timed, same entry point)
+        # ---- the other math modes on the headline workload (driver-timed, same entry point)
         out["modes"] = {}
         # (+ bf16: REDUCED precision -- conv operands rounded to bfloat16 as in BASELINE configs[2]; not a parity mode)
         for mode in ("f32x3", "f32", "bf16"):
@@ -319,47 +489,101 @@ def main():
                 continue
             w = Workload(net, x, mode, args.conf, args.nms)
             out["modes"][mode] = w.summary(w.run(sub_steps, sub_warm), sub_steps)
+            w.finish()
             if mode == "bf16":
                 out["modes"][mode]["note"] = "reduced precision (bf16 conv operands, fp32 accumulate / epilogue / decode): outside the 1e-4 parity bar"
             del w
         # ---- BASELINE.json configs (list indices): 1 = 416 bs32 fp32; 2 = 608 bs16 bf16 convs; 4 = 608 bs8 dense scene
-        out["configs"] = {}
+        out.setdefault("configs", {})
 
         def sub(key, label, net_, x_, mode, conf, nms, **kw):
             w = Workload(net_, x_, mode, conf, nms, **kw)
             s = w.summary(w.run(sub_steps, sub_warm), sub_steps)
-            B_ = x_.shape[0]
             s["workload"] = label
-            s["kept_per_img_first4"] = w.host_counts[B_:B_ + 4].tolist()
-            s["candidates_per_img_first4"] = w.host_counts[:4].tolist()
+            s["candidates_per_img_first4"], s["kept_per_img_first4"] = w.finish()
+            attach_traffic(s["roofline"], mode, x_.shape[2], x_.shape[0], s["roofline"]["launches"])
             out["configs"][key] = s
 
-        sub("1", "416x416 bs=32 SW-1 fp32-class (f32h2) conf=0.5 nms=0.4", net, scenes(32, 416, 1, dev, 32), "f32h2", 0.5, 0.4)
+        sub("1", "416x416 bs=32 SW-1 fp32-class (f32h2) conf=0.5 nms=0.4", net, scenes(32, 416, 1, dev), "f32h2", 0.5, 0.4)
         net608 = make_net(stream, 608, dev)
         sub("2", "608x608 bs=16 SW-1 bf16 convs / fp32 decode conf=0.5 nms=0.4", net608, scenes(16, 608, 2, dev), "bf16", 0.5, 0.4)
         del net608
         dnet = make_net(synth.dense_weight_stream(), 608, dev)
-        sub("4", "608x608 bs=8 SW-dense (>=5k pre-NMS rows/img) f32h2 conf=0.5 nms=0.4", dnet, scenes(8, 608, 4, dev, 8), "f32h2", 0.5, 0.4,
+        sub("4", "608x608 bs=8 SW-dense (>=5k pre-NMS rows/img) f32h2 conf=0.5 nms=0.4", dnet, scenes(8, 608, 4, dev), "f32h2", 0.5, 0.4,
             cap_host=8192)
         del dnet
         enet = make_net(synth.eval_weight_stream(), 416, dev)
-        sub("eval", "416x416 bs=32 SW-eval, eval mode as evaluate.py:201-204 (conf=0.005 nms=0.45 is_eval=True)", enet,
-            scenes(32, 416, 5, dev, 32), "f32h2", 0.005, 0.45, is_eval=True, cap_host=4096, max_cand=8192)
-        del enet
+        xe = scenes(32, 416, 5, dev)
+        sub("eval", "416x416 bs=32 SW-eval, eval mode as evaluate.py:201-204 (conf=0.005 nms=0.45 is_eval=True), Detector.run_device", enet,
+            xe, "f32h2", 0.005, 0.45, is_eval=True, cap_host=4096, max_cand=8192)
+        # the reference-shaped eval entry: evaluate.predict_and_process -> detect(is_eval=True) -> list of CPU tensors per batch
+        from yolo_v3_amd import evaluate as yeval
+
+        class CountBoxes(yeval.BatchHandler):
+            n = 0
+
+            def process_batch(self, sample, predictions):
+                CountBoxes.n += sum(int(p.shape[0]) for p in predictions if p.numel())
+
+        sample = {"img": xe, "org_img": [None] * 32, "img_path": ["%d.jpg" % i for i in range(32)]}
+        yeval.predict_and_process([sample] * 2, enet, 80, CountBoxes())                       # warm-up (buffers, lane calibration)
+        torch.cuda.synchronize()
+        CountBoxes.n = 0
+        t0 = time.perf_counter()
+        yeval.predict_and_process([sample] * sub_steps, enet, 80, CountBoxes())
+        torch.cuda.synchronize()
+        te = time.perf_counter() - t0
+        out["configs"]["eval_predict_and_process"] = {
+            "workload": "the same 32 images through evaluate.predict_and_process (reference evaluate.py:197-206): detect(is_eval=True) + list of "
+                        "per-image CPU tensors handed to a batch handler, %d batches" % sub_steps,
+            "value": round(32 * sub_steps / te, 2), "unit": "images/sec", "ms_per_step": round(te / sub_steps * 1e3, 4),
+            "boxes_per_batch": CountBoxes.n // sub_steps}
+        del enet, xe
         torch.cuda.empty_cache()
+
+    dog = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- BASELINE configs[0]: the letterboxed dog image (tests/golden/e2e.npz fixture: uint8 416x416x3), bs=1
+        import numpy as np
+        gpath = os.path.join(REPO, "tests", "golden", "e2e.npz")
+        if os.path.exists(gpath):
+            from yolo_v3_amd import Detector
+            g = np.load(gpath)
+            dog = torch.from_numpy(g["dog_u8"].astype(np.float32) / np.float32(255.0)).permute(2, 0, 1).unsqueeze(0).contiguous()
+            net416 = net if args.size == 416 and args.weights == "sw1" else make_net(synth.weight_stream(), 416, dev)
+            xd = dog.to(dev)
+            lat = {}
+            for name, graph in (("eager", False), ("hip_graph", True)):
+                d = Detector(net416, 1, 416, 416, 0.5, 0.4, graph=graph)
+                with torch.no_grad():
+                    for _ in range(5):
+                        res = d(xd)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        res = d(xd)                                  # full call: kernels + the one D2H sync + list conversion
+                    lat[name] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+                nbox = int(res[0].shape[0]) if res else 0
+                del d
+            out.setdefault("configs", {})["0"] = {"workload": "BASELINE configs[0]: dog-cycle-car.png letterboxed to 416x416 (fixture), bs=1, SW-1 weights, "
+                                                              "conf=0.5 nms=0.4, f32h2; latency of the whole detect call (kernels + D2H + list conversion), mean of 50",
+                                                  "gpu_ms_per_img": lat, "boxes": nbox}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.boxdelta import boxes_delta
         from yolo_v3_amd import detect
-        cb, xs, ref_boxes = cpu_baseline(stream, args.size, args.conf, args.nms)
+        cb, xs, ref_boxes = cpu_baseline(synth.weight_stream() if args.weights != "sw1" else stream, args.conf, args.nms, dog)
         out["cpu_baseline"] = cb
-        # NMS boxes delta vs ref: the product entry (detect) on the SAME sample the oracle just ran
+        if "configs" in out and "0" in out["configs"] and "dog_416x416_bs1" in cb["samples"]:
+            out["configs"]["0"]["cpu_ms_per_img"] = cb["samples"]["dog_416x416_bs1"]["ms_per_img"]
+        # NMS boxes delta vs ref: the product entry (detect) on the SAME 416x416 sample the oracle just ran
         from yolo_v3_amd import _ffi
-        net.math_mode = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3, "f32h2": _ffi.F32H2}[args.dtype]
-        got = detect(net, xs.to(dev), 80, args.conf, args.nms)
+        net416 = net if args.size == 416 and args.weights == "sw1" else make_net(synth.weight_stream(), 416, dev)
+        net416.math_mode = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3, "f32h2": _ffi.F32H2}[args.dtype]
+        got = detect(net416, xs.to(dev), 80, args.conf, args.nms)
         d = boxes_delta(got, ref_boxes, xs.shape[0])
         out["boxes_delta"] = {
-            "vs": "CPU oracle (reference path restated, oracle/oracle_cpu.py) on the cpu_baseline sample", "images": d["images"],
+            "vs": "CPU oracle (reference path restated, oracle/oracle_cpu.py) on the cpu_baseline 416x416 sample", "images": d["images"],
             "ref_boxes": d["ref_boxes"], "got_boxes": d["got_boxes"], "matched_iou_ge_0.999": d["matched"],
             "unmatched_frac": round(d["unmatched_frac"], 6), "count_equal_images": d["count_equal_images"],
             "class_equal_images": d["class_equal_images"], "max_rel_err_coords": float("%.3g" % d["max_rel_err_coords"]),

@@ -1,0 +1,44 @@
+"""bench.py's own N-rank launch path, on CPU: `python bench.py --gpus N` (no torchrun environment) must become N ranks,
+run the product's pack -> ONE all-gather -> assemble composition (--dry-run: CPU tensors over gloo, no kernels) and print one
+JSON line with n_gpus == N; without enough GPUs a real run must fail loudly, not fall back to one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, cwd=REPO, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_self_launch_two_ranks_dry_run():
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ok"] is True and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 8 and out["config"]["backend"] == "gloo"
+
+
+def test_one_rank_dry_run():
+    r = _run(["--dry-run", "--steps", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_too_few_gpus_is_an_error_not_a_one_rank_run():
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run(["--gpus", str(have + 2), "--no-extras", "--steps", "1"])
+    assert r.returncode == 2 and "visible GPUs" in r.stderr and "{" not in r.stdout
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr

@@ -53,22 +53,31 @@ def _worker(rank, world, port, q):
         meta[i, 0], meta[i, 1] = n, n
         bx[i, :n, 0] = float(g)
         bx[i, :n, 6] = torch.arange(n, dtype=torch.float32)
-    gb, gm = ydist.gather_boxes(bx, meta.view(-1))
-    res, status = ydist.assemble_global(gb, gm, spans, b_pad, max_cand=10, cap=cap2)
+    # the product composition: pack (boxes + one int32 meta row per image) -> ONE all-gather -> assemble
+    calls = []
+    orig = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    payload = ydist.pack_payload(bx, meta[:, 0], meta[:, 1], torch.zeros(1, dtype=torch.int32))
+    gathered = ydist.gather_payload(payload)
+    dist.all_gather_into_tensor = orig
+    ok = ok and len(calls) == 1 and gathered.shape == (world * b_pad, cap2 + 1, 7)
+    res, status = ydist.assemble_global(gathered, spans, b_pad, max_cand=10)
     ok = ok and status == 0 and len(res) == Bg
     for g in range(Bg):
         n = g % 3
         ok = ok and (tuple(res[g].shape) == ((n, 7) if n else (0,)))
         ok = ok and (n == 0 or bool((res[g][:, 0] == float(g)).all()))
     # nothing anywhere -> the [] sentinel; a status bit set on ONE rank is seen by all
-    meta0 = torch.zeros(b_pad, 3, dtype=torch.int32)
-    meta0[:, 2] = rank                                                  # rank r reports status r: everyone must see the OR
-    gb, gm = ydist.gather_boxes(torch.zeros(b_pad, cap2, 7), meta0.view(-1))
-    res0, status0 = ydist.assemble_global(gb, gm, spans, b_pad, 10, cap2)
+    zero = torch.zeros(b_pad, dtype=torch.int32)
+    payload0 = ydist.pack_payload(torch.zeros(b_pad, cap2, 7), zero, zero, torch.tensor([rank], dtype=torch.int32))   # rank r reports status r
+    res0, status0 = ydist.assemble_global(ydist.gather_payload(payload0), spans, b_pad, 10)
     want_status = 0
     for r_ in range(world):
         want_status |= r_
     ok = ok and res0 == [] and status0 == want_status
+    # rank-consistent lane count: MIN over the ranks of each rank's own calibration decision
+    from yolo_v3_amd.detect import _min_over_group
+    ok = ok and _min_over_group(2 if rank != world - 1 else 1, None, "cpu") == 1 and _min_over_group(2, None, "cpu") == 2
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

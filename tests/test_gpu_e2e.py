@@ -435,3 +435,61 @@ def test_two_lanes_are_bit_identical_to_one(sw1_stream, B, size):
     with pytest.raises(_ffi.Yv3Error, match="fp16 range"):
         two(bad)
     assert all(torch.equal(a, b) for a, b in zip(two(x), r1))   # and the detector is usable again afterwards
+
+
+@pytest.mark.gpu
+def test_repack_reaches_a_held_detector(sw1_stream):
+    """A write through ``param.data`` (the reference loader's idiom, darknet.py:275) is invisible to the (data_ptr, _version)
+    signature; ``net.repack()`` must invalidate the engine IN PLACE so that a Detector the caller already holds runs the
+    new weights (it used to keep an orphaned engine and silently run the stale ones).  Also: the position-sensitive
+    checksum mode sees a swap of two filters, which preserves every per-tensor L1 norm."""
+    net = load_sw1_net(sw1_stream).cuda()
+    x = torch.from_numpy(synth.images(2, 416, 6)).cuda()
+    det = Detector(net, 2, 416, 416)
+    det(x)
+    a = det.dets.clone()
+    bias = net.pre_det1.mlist[6].bias
+    bias.data.copy_(bias.data + 1.0)                          # does NOT bump bias._version
+    det(x)
+    assert torch.equal(det.dets, a)                           # documented: invisible without repack()
+    net.repack()
+    det(x)
+    assert not torch.equal(det.dets[:, :507], a[:, :507]) and torch.equal(det.dets[:, 507:], a[:, 507:])
+    assert torch.equal(net.forward_cat(x), det.dets)          # and net.forward sees the same engine state
+    # checksum mode: swap two filters of one conv through .data -- same L1 norm, different network
+    net.weight_check = "checksum"
+    b = net.forward_cat(x).clone()
+    w = net.feature.mlist[1].conv.weight
+    tmp = w.data[0].clone(); w.data[0].copy_(w.data[1]); w.data[1].copy_(tmp)
+    c = net.forward_cat(x)
+    assert not torch.equal(b, c)
+
+
+@pytest.mark.gpu
+def test_eval_detect_fused_equals_two_phase(sw1_stream):
+    """detect(is_eval=True) runs the fused Detector (16 384 candidate slots per image) and falls back to the two-phase
+    forward_cat -> postprocessing path on overflow; both give the same boxes, bit for bit, and alternating two batch shapes
+    re-uses the cached detectors (no re-allocation / re-calibration)."""
+    net = load_sw1_net(synth.eval_weight_stream()).cuda()
+    x = torch.from_numpy(synth.images(3, 416, 8)).cuda()
+    fused = detect(net, x, 80, 0.005, 0.45, is_eval=True)
+    two_phase = postprocessing(net.forward_cat(x), 80, 0.005, 0.45, True, True)
+    assert len(fused) == len(two_phase) == 3 and sum(len(b) for b in fused) > 100
+    for a, b in zip(fused, two_phase):
+        assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b)
+    # overflow of the fused buffers -> same answer through the fallback
+    from yolo_v3_amd import detect as dmod
+    key = [k for k in net._detectors if k[4] is True][0]
+    det = net._detectors[key]
+    det.max_cand_saved, det.max_cand = det.max_cand, 4        # pretend the candidate buffer was tiny
+    try:
+        again = detect(net, x, 80, 0.005, 0.45, is_eval=True)
+    finally:
+        det.max_cand = det.max_cand_saved
+    for a, b in zip(again, two_phase):
+        assert torch.equal(a, b)
+    ids = {k: id(v) for k, v in net._detectors.items()}
+    detect(net, x[:2], 80, 0.5, 0.4); detect(net, x, 80, 0.5, 0.4); detect(net, x[:2], 80, 0.5, 0.4)
+    assert len(net._detectors) <= dmod.DETECTOR_CACHE_MAX
+    detect(net, x, 80, 0.5, 0.4)
+    assert sum(1 for k, v in net._detectors.items() if ids.get(k) in (None, id(v))) == len(net._detectors)

@@ -66,7 +66,7 @@ if "graph32" in which:
         b, c = gd.run_device(x); print("run_device", it); sys.stdout.flush()
         torch.cuda.synchronize(); print("synced", it); sys.stdout.flush()
         h = c.cpu(); print("counts", h[:4].tolist(), h[32:36].tolist()); sys.stdout.flush()
-        r = gd.pp.to_list(b, h); print("list ok", all(torch.equal(a, e) for a, e in zip(r, r0))); sys.stdout.flush()
+        r = gd.to_list(b, h); print("list ok", all(torch.equal(a, e) for a, e in zip(r, r0))); sys.stdout.flush()
 
 pieces = [w.split(":")[1] for w in which if w.startswith("piece:")]
 if pieces:
@@ -86,9 +86,9 @@ if pieces:
         with torch.cuda.graph(gr):
             if piece == "convs": d.engine.run_convs(d.plan, st, d.dets)
             elif piece == "decode": d.engine.run_decode(d.plan, d.dets)
-            elif piece == "filter": d.pp.filter(d.dets, 0.5, False, True)
-            elif piece == "nms": d.pp.nms(d.dets, 0.4, True, d.pp.max_cand, d.pp.cap)
+            elif piece == "filter": d.lane_pp[0].filter(d.dets, 0.5, False, True)
+            elif piece == "nms": d.lane_pp[0].nms(d.dets, 0.4, True, d.max_cand, d.cap)
             else: d._enqueue(st)
         for it in range(4):
             gr.replay(); torch.cuda.synchronize()
-            print("replayed", piece, it, d.pp.counts.cpu()[:4].tolist()); sys.stdout.flush()
+            print("replayed", piece, it, d.counts.cpu()[:4].tolist()); sys.stdout.flush()

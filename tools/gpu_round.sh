@@ -20,9 +20,10 @@ pmc)   for c in MFMA FETCH WRITE; do
        python tools/mfma_util_summary.py $O/${TAG}_pmc_MFMA > $O/${TAG}_mfma_util.json; cat $O/${TAG}_mfma_util.json | head -60
        python tools/traffic_summary.py $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE 4 71 > $O/${TAG}_traffic_f32h2_416_bs64.json; cat $O/${TAG}_traffic_f32h2_416_bs64.json
        rm -rf $O/${TAG}_pmc_MFMA $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE ;;
-rehearse) # the driver's N>1 launch line with 2 ranks on this ONE GPU (gloo carries the gather: RCCL refuses two ranks per device).
-       # --lanes 1: two PROCESSES sharing a GPU oversubscribe its hardware queues once each also runs two lanes (tools/rehearse_probe.sh:
-       # 900 ms/step instead of 30); one process per GPU -- the real launch -- is what lanes are calibrated for
-       YV3_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
-           bench.py --gpus 2 --steps 10 --warmup 3 --lanes 1 > $O/${TAG}_bench_2rank_gloo_rehearsal.json 2> $O/${TAG}_rehearse.err; tail -c 400 $O/${TAG}_bench_2rank_gloo_rehearsal.json; tail -2 $O/${TAG}_rehearse.err ;;
+rehearse) # bench.py's OWN N-rank launch (python bench.py --gpus 2 re-launches itself under torch.distributed.run) with 2 ranks on this ONE GPU
+       # (gloo carries the gather: RCCL refuses two ranks per device).  --lanes 1: two PROCESSES sharing a GPU oversubscribe its hardware
+       # queues once each also runs two lanes; one process per GPU -- the real launch -- is what lanes are calibrated for.
+       # First the failure mode: without the override a 2-GPU request on a 1-GPU box must be an error, not a 1-rank run.
+       python bench.py --gpus 2 --no-extras > $O/${TAG}_bench_2gpus_on_1gpu_box.out 2> $O/${TAG}_bench_2gpus_on_1gpu_box.err; echo "rc=$?" >> $O/${TAG}_bench_2gpus_on_1gpu_box.err; tail -2 $O/${TAG}_bench_2gpus_on_1gpu_box.err
+       YV3_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --lanes 1 > $O/${TAG}_bench_2rank_gloo_rehearsal.json 2> $O/${TAG}_rehearse.err; tail -c 600 $O/${TAG}_bench_2rank_gloo_rehearsal.json; tail -2 $O/${TAG}_rehearse.err ;;
 esac; done

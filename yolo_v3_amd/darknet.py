@@ -269,15 +269,17 @@ class YoloNet(nn.Module):
         return eng
 
     def repack(self):
-        """Drop packed weights, plans and cached detectors; the next forward re-packs from the current parameters.
+        """Invalidate packed weights and plans IN PLACE; the next forward re-packs from the current parameters.  A
+        `Detector` (or engine) the caller already holds sees the change too: it keeps its Engine object, whose
+        generation counter moves with the re-pack.
 
         Packed weights follow the parameters automatically for everything that changes a parameter's
         ``(data_ptr, _version)``: ``load_state_dict``, ``loadWeight`` / ``WeightManager``, assignments, in-place ops on
         the parameter.  Writes through ``param.data`` (``p.data.copy_(..)``, the reference loader's idiom,
         darknet.py:275) are invisible to that check: call ``repack()`` after them, or set
         ``net.weight_check = "checksum"`` (engine.Engine._signature)."""
-        self._engines = {}
-        self.__dict__.pop("_detectors", None)
+        for eng in self._engines.values():
+            eng.invalidate()
 
     def load_state_dict(self, state_dict, *args, **kwargs):
         out = super().load_state_dict(state_dict, *args, **kwargs)

@@ -20,19 +20,24 @@ the 26x26 layers 2.64, ...) and overlap HBM-bound layers with matrix-bound ones:
 keeps the fastest -- or a single lane if none wins.
 """
 import time
+from collections import OrderedDict
 
 import torch
+import torch.distributed as dist
 
 from . import _ffi
 from .engine import Plan
-from .utils import PostProcessor
+from .utils import PostProcessor, boxes_to_list
 
 
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
-                 max_cand=None, cap=None, dtype=None, graph=False, lanes=None):
+                 max_cand=None, cap=None, dtype=None, graph=False, lanes=None, group=None, sync_lanes=False):
         """lanes: 1, 2, or None = automatic (2 when the batch is at least ~12 images of 416 x 416 and a stream pair that really
-        runs concurrently is found, see the module docstring; ``net.lanes`` / YV3_LANES override the default)."""
+        runs concurrently is found, see the module docstring; ``net.lanes`` / YV3_LANES override the default).
+        sync_lanes: all ranks of the torch.distributed process group `group` (None = the default group) construct this
+        Detector together (`detect_sharded`); the automatic lane decision is then MIN-reduced over them so that every
+        rank runs the same lane count."""
         self.net = net
         self.shape = (batch, 3, height, width)
         self.conf, self.nms_thr, self.is_eval, self.use_nms = obj_conf_thr, nms_thr, is_eval, use_nms
@@ -40,97 +45,143 @@ class Detector:
         self.engine.ensure_packed()
         self.device = self.engine.device
         self._generation = self.engine.generation
+        self._group, self._sync_lanes = group, bool(sync_lanes)
         if lanes is None:
             import os
             lanes = getattr(net, "lanes", None) or (int(os.environ["YV3_LANES"]) if os.environ.get("YV3_LANES") else None)
         self._lanes_req = lanes
         with torch.cuda.device(self.device):
+            B = batch
+            probe = Plan.geometry(self.engine, height, width)            # (rows N, attributes) without allocating a plan
+            n, attrib = probe
+            self.N = n
+            self.max_cand = int(max_cand or (min(n * net.numClass, 16384) if is_eval else n))
+            self.cap = int(cap or self.max_cand)
+            self.dets = torch.empty((B, n, attrib), device=self.device, dtype=torch.float32)
+            # ONE result tensor + ONE counts buffer ([0:B] candidates, [B:2B] kept) for all lanes: a single D2H copy
+            self.boxes = torch.empty((B, self.cap, 7), device=self.device, dtype=torch.float32)
+            self.counts = torch.zeros(2 * B, device=self.device, dtype=torch.int32)
             # automatic: worth trying from ~12 images of 416 x 416 upwards (measured crossover; 608 x 608: 8), calibration decides
             auto2 = lanes is None and batch >= 2 and batch * height * width >= 12 * 416 * 416
-            self._build_plans(2 if auto2 or (lanes or 1) >= 2 else 1)
-            self.dets = torch.empty((batch, self.plan.N, self.plan.attrib), device=self.device, dtype=torch.float32)
-            n = self.plan.N
-            self.pp = PostProcessor(batch, n, net.numClass, self.device,
-                                    max_cand=max_cand or (min(n * net.numClass, 16384) if is_eval else n), cap=cap)
-            if self.lanes > 1 and lanes is None:
-                self._calibrate_lanes()
+            self.lane_calibration = None
+            if auto2:
+                self._choose_lanes()
+            else:
+                self._build_plans(2 if (lanes or 1) >= 2 else 1)
         self._graph = None
         self._static_in = None
         self._want_graph = graph
-        self.boxes = None
 
     # -- lanes
-    def _build_plans(self, lanes):
+    def _build_plans(self, lanes, streams=None):
+        """Per lane: a Plan (activation buffers + descriptors) for its contiguous sub-batch, a HIP stream and a
+        PostProcessor whose outputs are views of the Detector's result tensor / counts buffer."""
         B, _, H, W = self.shape
         lanes = max(1, min(int(lanes), B))
         self.lanes = lanes
+        nc = self.net.numClass
         if lanes == 1:
             self.plan = self.engine.plan(B, H, W)                 # the engine's cached plan (shared with net.forward)
             self.lane_plans, self.lane_off, self.lane_streams = [self.plan], [0], []
-            return
-        sizes = [B // lanes + (1 if i < B % lanes else 0) for i in range(lanes)]
-        flags = torch.zeros(1, device=self.device, dtype=torch.int32)
-        self.lane_plans = [Plan(self.engine, b, H, W, flags=flags) for b in sizes]     # own buffers per lane, ONE status word
-        self.lane_off = [sum(sizes[:i]) for i in range(lanes)]
-        self.lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
-        self.plan = self.lane_plans[0]
+        else:
+            sizes = [B // lanes + (1 if i < B % lanes else 0) for i in range(lanes)]
+            flags = torch.zeros(1, device=self.device, dtype=torch.int32)
+            self.lane_plans = [Plan(self.engine, b, H, W, flags=flags) for b in sizes]     # own buffers per lane, ONE status word
+            self.lane_off = [sum(sizes[:i]) for i in range(lanes)]
+            self.lane_streams = streams or [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
+            self.plan = self.lane_plans[0]
+        self.lane_pp = [PostProcessor(p.B, self.N, nc, self.device, max_cand=self.max_cand, cap=self.cap,
+                                      counts=(self.counts[off:off + p.B], self.counts[B + off:B + off + p.B]),
+                                      out=self.boxes[off:off + p.B])
+                        for p, off in zip(self.lane_plans, self.lane_off)]
 
-    def _run_convs(self, x, mark):
-        """conv0 ... head convs (+ decode) of every lane; returns on the current stream with all lanes joined."""
+    def _lane_body(self, p, pp, xi, di, mark, post=True):
+        """One lane's whole pipeline on the current stream: front -> convs (+ decode) -> filter -> NMS."""
+        self.engine.run_front(p, xi)
+        mark("conv0")
+        self.engine.run_conv_sequence(p, di)
+        mark("convs")
+        self.engine.run_decode(p, di)
+        mark("decode")
+        if not post:
+            return
+        # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
+        pp.filter(di, self.conf, self.is_eval, prob=True)
+        mark("filter")
+        pp.nms(di, self.nms_thr, self.use_nms, self.max_cand, self.cap)
+        mark("nms")
+
+    def _run_lanes(self, x, mark, post=True):
+        """Every lane's pipeline; returns on the current stream with all lanes joined.  With two lanes each lane runs its
+        OWN filter + NMS on its own stream, so one lane's post-processing overlaps the other lane's convolutions (the
+        dense-scene configuration spends 19 % of a step there); the stage marks of a multi-lane step are 'conv0' = fork,
+        'convs' ... 'nms' = join (all of it is the concurrent section)."""
+        noop = lambda name: None
         if self.lanes == 1:
-            self.engine.run_front(self.plan, x)
-            mark("conv0")
-            self.engine.run_conv_sequence(self.plan, self.dets)
-            mark("convs")
-            self.engine.run_decode(self.plan, self.dets)
+            self._lane_body(self.plan, self.lane_pp[0], x, self.dets, mark, post)
             return
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
-        mark("conv0")                                             # (lanes: the front kernels are part of the 'convs' stage)
-        for p, off, st in zip(self.lane_plans, self.lane_off, self.lane_streams):
+        mark("conv0")
+        for p, pp, off, st in zip(self.lane_plans, self.lane_pp, self.lane_off, self.lane_streams):
             st.wait_event(fork)
             with torch.cuda.stream(st):
-                xi, di = x[off:off + p.B], self.dets[off:off + p.B]
-                self.engine.run_front(p, xi)
-                self.engine.run_conv_sequence(p, di)
-                self.engine.run_decode(p, di)
+                self._lane_body(p, pp, x[off:off + p.B], self.dets[off:off + p.B], noop, post)
                 done = torch.cuda.Event()
                 done.record(st)
             main.wait_event(done)
-        mark("convs")
+        for name in ("convs", "decode", "filter", "nms"):
+            mark(name)
+
+    def _choose_lanes(self):
+        """Automatic lane count: time the candidate stream pairs against one lane on this GPU (streams that share a
+        hardware queue serialise and LOSE against a single lane) -- once per (engine, batch shape): the decision and the
+        winning stream pair are cached on the engine -- then agree on MIN over the ranks of `group`."""
+        key = ("lanes", self.shape, self.is_eval)
+        cached = self.engine.lane_choices.get(key)
+        if cached is None:
+            cached = self._calibrate_lanes()
+            self.engine.lane_choices[key] = cached
+        lanes, streams, self.lane_calibration = cached
+        if self._sync_lanes:
+            lanes = _min_over_group(lanes, self._group, self.device)
+        self._build_plans(lanes, streams if lanes > 1 else None)
 
     def _calibrate_lanes(self):
-        """Keep the stream pair that really runs the two lanes concurrently on this GPU (streams that share a hardware queue
-        serialise and LOSE against a single lane); fall back to one lane if no candidate beats it."""
         B, _, H, W = self.shape
         x = torch.zeros(self.shape, device=self.device, dtype=torch.float32)
         noop = lambda name: None
 
         def timed(n=3):
             for _ in range(2):
-                self._run_convs(x, noop)
+                self._run_lanes(x, noop, post=False)
             torch.cuda.synchronize(self.device)
             t0 = time.perf_counter()
             for _ in range(n):
-                self._run_convs(x, noop)
+                self._run_lanes(x, noop, post=False)
             torch.cuda.synchronize(self.device)
             return (time.perf_counter() - t0) / n
 
-        two_plans, two_off = self.lane_plans, self.lane_off
-        cands = [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]
         best = None
-        for pair in cands:
+        self._build_plans(2)
+        plans2 = (self.lane_plans, self.lane_off, self.lane_pp)
+        for pair in [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]:
             self.lane_streams = pair
             t = timed()
             if best is None or t < best[0]:
                 best = (t, pair)
+        had_plan = (B, H, W) in self.engine._plans
         self._build_plans(1)
         t1 = timed()
-        self.lane_calibration = {"one_lane_ms": round(t1 * 1e3, 3), "two_lanes_ms": round(best[0] * 1e3, 3)}
-        if best[0] < 0.97 * t1:
-            self.lanes, self.lane_plans, self.lane_off, self.lane_streams, self.plan = 2, two_plans, two_off, best[1], two_plans[0]
         self.plan.flags.zero_()
+        plans2[0][0].flags.zero_()
+        two = best[0] < 0.97 * t1
+        if two and not had_plan:
+            self.engine.drop_plan(B, H, W)            # the one-lane plan's activation buffers are not kept alive beside the lanes'
+        del plans2
+        return (2 if two else 1, best[1] if two else None,
+                {"one_lane_ms": round(t1 * 1e3, 3), "two_lanes_ms": round(best[0] * 1e3, 3)})
 
     # -- pipeline pieces (all asynchronous on the current stream)
     def _enqueue(self, x, mark=None):
@@ -138,13 +189,7 @@ class Detector:
         stream there: per-stage split conv0 / convs / decode / filter / nms)."""
         mark = mark or (lambda name: None)
         mark("start")
-        self._run_convs(x, mark)
-        mark("decode")
-        # scores are sigmoid products: PP_PROB lets the filter skip rows whose objectness already fails
-        self.pp.filter(self.dets, self.conf, self.is_eval, prob=True)
-        mark("filter")
-        self.boxes = self.pp.nms(self.dets, self.nms_thr, self.use_nms, self.pp.max_cand, self.pp.cap)
-        mark("nms")
+        self._run_lanes(x, mark)
 
     def _capture(self, x):
         self._static_in = torch.empty_like(x)
@@ -169,10 +214,7 @@ class Detector:
             self.engine.ensure_packed()
             if self.engine.generation != self._generation:      # parameters changed: packed weights / plans were rebuilt
                 self._generation = self.engine.generation
-                streams = self.lane_streams
-                self._build_plans(self.lanes)
-                if streams:
-                    self.lane_streams = streams                 # keep the calibrated pair
+                self._build_plans(self.lanes, self.lane_streams or None)     # keep the calibrated pair
                 self._graph = None
             if self._want_graph:
                 if self._graph is None:
@@ -181,34 +223,72 @@ class Detector:
                 self._graph.replay()
             else:
                 self._enqueue(x, mark)
-        return self.boxes, self.pp.counts
+        return self.boxes, self.counts
+
+    def to_list(self, boxes, counts_host):
+        return boxes_to_list(boxes, counts_host, self.shape[0], self.max_cand)
 
     def __call__(self, imgs):
         boxes, counts = self.run_device(imgs)
         host = torch.cat((counts, self.plan.flags)).cpu()    # the single D2H sync: counts + saturation flag
         self.engine.raise_if_overflowed(self.plan, int(host[-1]))
-        return self.pp.to_list(boxes, host[:-1])
+        return self.to_list(boxes, host[:-1])
+
+
+def _min_over_group(value, group, device):
+    """MIN of an int over the ranks of `group` (on the backend's device: RCCL wants GPU tensors, gloo CPU ones)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([int(value)], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def _detector_cache(net):
+    """At most DETECTOR_CACHE_MAX detectors (buffers of ~10 GB each at bs=64) per net, least recently used first out:
+    alternating between two batch shapes (a last partial batch) does not re-allocate or re-calibrate."""
+    return net.__dict__.setdefault("_detectors", OrderedDict())
+
+
+DETECTOR_CACHE_MAX = 3
+
+
+def cached_detector(net, key, build):
+    cache = _detector_cache(net)
+    det = cache.get(key)
+    if det is None:
+        while len(cache) >= DETECTOR_CACHE_MAX:
+            cache.popitem(last=False)
+        det = cache[key] = build()
+    else:
+        cache.move_to_end(key)
+    return det
 
 
 def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True):
-    """``postprocessing(torch.cat(net(imgs, None), 1), ...)`` fused on the GPU (see module docstring)."""
+    """``postprocessing(torch.cat(net(imgs, None), 1), ...)`` fused on the GPU (see module docstring).
+
+    Eval mode (``is_eval=True``: every (row, class) pair above the threshold is a candidate, up to N*C per image) runs the
+    same fused `Detector` with room for 16 384 candidates per image; a batch that exceeds it is re-run through the
+    two-phase path (`forward_cat` -> `postprocessing`, buffers sized from the actual counts, one more host sync)."""
     if num_classes is not None and num_classes != net.numClass:
         raise _ffi.Yv3Error("num_classes=%d does not match net.numClass=%d" % (num_classes, net.numClass))
     _ffi.require_cuda(imgs, "imgs")
-    if is_eval:
-        # multi-label mode can produce up to N*C candidates per image: size the buffers from the
-        # actual counts (one extra host sync) instead of the worst case
-        from .utils import postprocessing
-        with torch.no_grad():
-            return postprocessing(net.forward_cat(imgs), net.numClass, obj_conf_thr, nms_thr, True, use_nms)
     key = (tuple(imgs.shape), imgs.device, float(obj_conf_thr), float(nms_thr), bool(is_eval), bool(use_nms), net.math_mode)
-    cache = net.__dict__.setdefault("_detectors", {})
-    det = cache.get(key)
-    if det is None:
-        cache.clear()                                        # keep at most one set of buffers alive
-        det = cache[key] = Detector(net, imgs.shape[0], imgs.shape[2], imgs.shape[3], obj_conf_thr, nms_thr, is_eval, use_nms)
+    det = cached_detector(net, key, lambda: Detector(net, imgs.shape[0], imgs.shape[2], imgs.shape[3], obj_conf_thr, nms_thr,
+                                                     is_eval, use_nms))
     with torch.no_grad():
-        return det(imgs)
+        if not is_eval:
+            return det(imgs)
+        boxes, counts = det.run_device(imgs)
+        host = torch.cat((counts, det.plan.flags)).cpu()
+        det.engine.raise_if_overflowed(det.plan, int(host[-1]))
+        B = imgs.shape[0]
+        if int(host[:B].max()) <= det.max_cand and int(host[B:2 * B].max()) <= det.cap:
+            return det.to_list(boxes, host[:-1])
+        from .utils import postprocessing
+        return postprocessing(det.dets, net.numClass, obj_conf_thr, nms_thr, True, use_nms)
 
 
 def predict(net, images, dim=(416, 416), num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_letterbox=True):

@@ -3,9 +3,11 @@
 The reference is single-GPU (no torch.distributed / DataParallel anywhere).  Images are
 independent on this path (convs, decode and NMS are all per image; utils.py:152 loops
 ``for batch_idx in range(nB)``), so scaling out is: one process per GPU, contiguous batch shards,
-replicated weights, and ONE exchange at the very end -- an all-gather of the fixed-capacity
-``[B_local, cap, 7]`` box tensor and the per-image counts over RCCL/xGMI (``backend="nccl"`` is
-RCCL on ROCm).  ~0.1-1 MB per rank: latency-bound, no ring all-reduce anywhere.
+replicated weights, and ONE exchange at the very end -- a single ``all_gather_into_tensor`` of the
+fixed-capacity ``[B_local, cap + 1, 7]`` payload (``cap`` box rows + one row carrying the image's
+int32 candidate count, kept count and the rank's kernel status word, bit-cast into the fp32 row)
+over RCCL/xGMI (``backend="nccl"`` is RCCL on ROCm).  ~0.1-1 MB per rank: latency-bound, no ring
+all-reduce anywhere.
 The same code runs on CPU tensors with the ``gloo`` backend (tests/test_dist_gloo.py).
 """
 import os
@@ -39,23 +41,22 @@ def init_from_env(backend=None):
 
 
 def gather_boxes(boxes, counts, group=None, force=False):
-    """All-gather equal-shaped shards.
-
-    boxes  [B_local, cap, 7] float32, counts [B_local] int32 (number of valid rows per image).
-    Returns (boxes [world*B_local, cap, 7], counts [world*B_local]) in rank order on every rank.
-    A world of one returns its inputs; ``force=True`` runs the collective even then (exercises RCCL on a
-    single GPU: tests/test_gpu_dist.py).
-    """
+    """All-gather equal-shaped shards of boxes ``[B_local, cap, 7]`` + int32 ``counts [B_local]`` (or ``[B_local*k]``
+    flattened rows of k <= 7 int32 per image) with ONE collective: the counts ride in an extra box row (`pack_payload`'s
+    layout).  Returns (boxes [world*B_local, cap, 7], counts [world*B_local*k]) in rank order on every rank.  A world
+    of one returns its inputs; ``force=True`` runs the collective even then (tests/test_gpu_dist.py)."""
     if not dist.is_available() or not dist.is_initialized():
         return boxes, counts
     if dist.get_world_size(group) == 1 and not force:
         return boxes, counts
-    world = dist.get_world_size(group)
-    all_boxes = torch.empty((world * boxes.shape[0],) + tuple(boxes.shape[1:]), dtype=boxes.dtype, device=boxes.device)
-    all_counts = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(all_boxes, boxes.contiguous(), group=group)      # concatenated along dim 0
-    dist.all_gather_into_tensor(all_counts, counts.contiguous(), group=group)
-    return all_boxes, all_counts
+    B, cap = boxes.shape[0], boxes.shape[1]
+    k = counts.numel() // max(B, 1)
+    assert k * B == counts.numel() and 1 <= k <= 7, "counts must hold 1..7 int32 per image"
+    payload = torch.zeros((B, cap + 1, 7), dtype=torch.float32, device=boxes.device)
+    payload[:, :cap].copy_(boxes)
+    payload[:, cap].view(torch.int32)[:, :k].copy_(counts.view(B, k))
+    out = gather_payload(payload, group, force)
+    return out[:, :cap].contiguous(), out[:, cap].view(torch.int32)[:, :k].reshape(-1).contiguous()
 
 
 def boxes_to_list(boxes, counts, cand_counts=None):
@@ -86,30 +87,110 @@ def take_shard(imgs, rank, world, local_shard=False):
     return x, b_pad, spans
 
 
-def assemble_global(all_boxes, all_meta, spans, b_pad, max_cand, cap):
-    """Gathered ``[world*b_pad, cap, 7]`` boxes + ``[world*b_pad, 3]`` int32 meta rows (candidates, kept, status) ->
-    the reference's result convention for the GLOBAL batch (list of ``[n,7]`` CPU tensors in image order, an empty
-    ``torch.Tensor()`` for an image without candidates, ``[]`` when no image has any: utils.py:153-158,248-251).
+META_FIELDS = 3          # int32 per image in the payload's last row: candidates, kept, status word
+
+
+def pack_payload(boxes, cand_counts, kept_counts, status, payload=None):
+    """``boxes [B, >=cap, 7]`` fp32 + per-image int32 counts + the rank's status word (0-dim / 1-element int32 tensor)
+    -> ``payload [B, cap+1, 7]`` fp32: rows ``[0, cap)`` are the boxes, row ``cap`` holds the three int32 values
+    bit-cast into its first three floats.  ``payload`` (pre-allocated) fixes ``cap``; all on the tensors' device."""
+    B = boxes.shape[0]
+    if payload is None:
+        payload = torch.empty((B, boxes.shape[1] + 1, 7), dtype=torch.float32, device=boxes.device)
+    cap = payload.shape[1] - 1
+    payload[:, :cap].copy_(boxes[:, :cap])
+    meta = payload[:, cap].view(torch.int32)              # [B, 7] int32 view of the last row (same storage)
+    meta[:, 0].copy_(cand_counts)
+    meta[:, 1].copy_(kept_counts)
+    meta[:, 2].copy_(status.reshape(-1)[:1].expand(B))
+    meta[:, 3:].zero_()
+    return payload
+
+
+def unpack_payload(payload):
+    """-> (boxes view ``[B, cap, 7]`` fp32, meta ``[B, 3]`` int32: candidates, kept, status)."""
+    cap = payload.shape[1] - 1
+    return payload[:, :cap], payload[:, cap].view(torch.int32)[:, :META_FIELDS]
+
+
+def gather_payload(payload, group=None, force=False, out=None):
+    """THE collective of the sharded path: one ``all_gather_into_tensor`` of the equal-shaped payloads, rank order along
+    dim 0.  A world of one returns its input (``force=True`` runs the collective even then: tests/test_gpu_dist.py)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return payload
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return payload
+    if out is None:
+        out = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(out, payload.contiguous(), group=group)
+    return out
+
+
+def assemble_global(gathered, spans, b_pad, max_cand):
+    """Gathered ``[world*b_pad, cap+1, 7]`` payload -> the reference's result convention for the GLOBAL batch (list of
+    ``[n,7]`` CPU tensors in image order, an empty ``torch.Tensor()`` for an image without candidates, ``[]`` when no
+    image has any: utils.py:153-158,248-251).  The host copy of the meta rows is the path's single host sync.
     Returns (result, status word OR-ed over all ranks)."""
     from . import _ffi
-    all_meta = all_meta.view(-1, 3).cpu()
+    boxes, meta = unpack_payload(gathered)
+    cap = boxes.shape[1]
+    meta = meta.cpu()
     status = 0
-    for v in all_meta[:, 2].tolist():
+    for v in meta[:, 2].tolist():
         status |= int(v)
     keep = []
     for r, (l, h) in enumerate(spans):
         keep += list(range(r * b_pad, r * b_pad + (h - l)))
     if not keep:
         return [], status
-    ncand, nkeep = all_meta[keep, 0].tolist(), all_meta[keep, 1].tolist()
+    ncand, nkeep = meta[keep, 0].tolist(), meta[keep, 1].tolist()
     if max(ncand) > max_cand:
         raise _ffi.Yv3Error("candidate buffer overflow (%d > %d)" % (max(ncand), max_cand))
     if max(nkeep) > cap:
         raise _ffi.Yv3Error("more than cap=%d boxes kept for one image (%d): raise cap" % (cap, max(nkeep)))
     if sum(ncand) == 0:
         return [], status
-    host = all_boxes[:, :max(max(nkeep), 1)].cpu()
+    host = boxes[:, :max(max(nkeep), 1)].cpu()
     return [host[i, :nkeep[j]].clone() if ncand[j] else torch.Tensor() for j, i in enumerate(keep)], status
+
+
+class ShardedDetector:
+    """This rank's share of a sharded detection: the fused single-GPU `Detector` for ``b_pad`` images + the payload
+    buffers of the final gather.  `run_device` enqueues everything up to and including the collective and returns the
+    gathered payload on the GPU (no host sync); `assemble` turns it into the reference's list (the one host sync).
+    `detect_sharded` is ``assemble(run_device(shard))``; `bench.py --gpus N` times `run_device` (+ the D2H copy)."""
+
+    def __init__(self, net, b_pad, height, width, obj_conf_thr=0.5, nms_thr=0.4, use_nms=True, cap=512, dtype=None,
+                 group=None, force_collective=False, lanes=None):
+        from .detect import Detector
+        self.group, self.force = group, force_collective
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        # every rank builds this together: the automatic lane count is MIN-reduced over the group (rank-consistent)
+        self.det = Detector(net, b_pad, height, width, obj_conf_thr, nms_thr, False, use_nms, cap=cap, dtype=dtype,
+                            lanes=lanes, group=group, sync_lanes=on and self.world > 1)
+        self.b_pad = b_pad
+        self.cap = min(int(cap), self.det.cap)
+        dev = self.det.device
+        self.payload = torch.empty((b_pad, self.cap + 1, 7), dtype=torch.float32, device=dev)
+        self.gathered = (torch.empty((self.world * b_pad, self.cap + 1, 7), dtype=torch.float32, device=dev)
+                         if (self.world > 1 or force_collective) else None)
+
+    def run_device(self, x, mark=None):
+        det = self.det
+        boxes, counts = det.run_device(x, mark)
+        with torch.cuda.device(det.device):
+            pack_payload(boxes, counts[:self.b_pad], counts[self.b_pad:], det.plan.flags, self.payload)
+            out = gather_payload(self.payload, self.group, self.force, self.gathered)
+            if mark is not None:
+                mark("gather")
+        return out
+
+    def assemble(self, gathered, spans):
+        result, status = assemble_global(gathered, spans, self.b_pad, self.det.max_cand)
+        self.det.engine.raise_if_overflowed(self.det.plan, status)
+        return result
 
 
 def detect_sharded(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, use_nms=True, group=None,
@@ -120,14 +201,14 @@ def detect_sharded(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, u
     Every rank passes the SAME global batch ``imgs`` [B,3,H,W] (CPU or GPU; only the rank's contiguous shard
     ``shard_range(B, rank, world)`` is moved to its GPU and run) -- or, with ``local_shard=True``, its own shard
     of equal size on every rank.  Each rank runs the fused single-GPU pipeline (`Detector.run_device`: 75 convs ->
-    decode -> filter -> NMS, no host sync) on its shard; the ONLY exchange is one all-gather of the fixed-capacity
-    ``[B_local, cap, 7]`` boxes + candidate / kept counts over RCCL/xGMI (`gather_boxes`).  Returns, on every
-    rank, exactly what ``detect`` returns for the global batch: the reference's list of per-image ``[n,7]`` CPU
-    tensors in global image order, or ``[]`` (test.py:35-36 / utils.py:248).  Without an initialised process group
-    it is ``detect`` on one GPU.  ``cap`` bounds the kept boxes per image that travel (overflow raises).
-    """
+    decode -> filter -> NMS, no host sync) on its shard; the ONLY exchange is ONE all-gather of the fixed-capacity
+    ``[B_local, cap+1, 7]`` payload (boxes + a row with the candidate / kept counts and the status word) over
+    RCCL/xGMI.  Returns, on every rank, exactly what ``detect`` returns for the global batch: the reference's list of
+    per-image ``[n,7]`` CPU tensors in global image order, or ``[]`` (test.py:35-36 / utils.py:248).  Without an
+    initialised process group it is ``detect`` on one GPU.  ``cap`` bounds the kept boxes per image that travel
+    (overflow raises).  All ranks must call it together (it contains collectives)."""
     from . import _ffi
-    from .detect import Detector
+    from .detect import cached_detector
     if num_classes is not None and num_classes != net.numClass:
         raise _ffi.Yv3Error("num_classes=%d does not match net.numClass=%d" % (num_classes, net.numClass))
     on = dist.is_available() and dist.is_initialized()
@@ -138,18 +219,9 @@ def detect_sharded(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, u
         raise _ffi.Yv3Error("YoloNet parameters must live on this rank's GPU (net.cuda())")
     x, b_pad, spans = take_shard(imgs, rank, world, local_shard)
     x = x.to(dev, non_blocking=True).float().contiguous()
-    key = ("sharded", b_pad, tuple(x.shape[1:]), float(obj_conf_thr), float(nms_thr), bool(use_nms), int(cap), dtype, net.math_mode)
-    cache = net.__dict__.setdefault("_detectors", {})
-    det = cache.get(key)
-    if det is None:
-        cache.clear()
-        det = cache[key] = Detector(net, b_pad, x.shape[2], x.shape[3], obj_conf_thr, nms_thr, False, use_nms, cap=cap, dtype=dtype)
-    with torch.no_grad(), torch.cuda.device(dev):
-        boxes, counts = det.run_device(x)
-        cap_ = min(cap, boxes.shape[1])
-        # one int32 row per image: candidates, kept, the status word (fp16 saturation flag) of this rank's kernels
-        meta = torch.stack((counts[:b_pad], counts[b_pad:], det.plan.flags.expand(b_pad)), 1).contiguous()
-        all_boxes, all_meta = gather_boxes(boxes[:, :cap_].contiguous(), meta.view(-1), group, force_collective)
-        result, status = assemble_global(all_boxes, all_meta, spans, b_pad, det.pp.max_cand, cap_)   # the single host sync
-    det.engine.raise_if_overflowed(det.plan, status)
-    return result
+    key = ("sharded", b_pad, tuple(x.shape[1:]), float(obj_conf_thr), float(nms_thr), bool(use_nms), int(cap), dtype,
+           net.math_mode, bool(force_collective), id(group))
+    sd = cached_detector(net, key, lambda: ShardedDetector(net, b_pad, x.shape[2], x.shape[3], obj_conf_thr, nms_thr, use_nms,
+                                                           cap, dtype, group, force_collective))
+    with torch.no_grad():
+        return sd.assemble(sd.run_device(x), spans)                       # assemble: the single host sync

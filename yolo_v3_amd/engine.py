@@ -195,6 +195,13 @@ def out_hw(h, w, k, stride):
 class Plan:
     """Buffers + kernel descriptors for one (B, H, W)."""
 
+    @staticmethod
+    def geometry(engine, H, W):
+        """(detection rows N per image, attributes 5+C) of a plan for H x W inputs, without allocating one."""
+        if H % 32 or W % 32:
+            raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
+        return 3 * sum((H // s) * (W // s) for s in (32, 16, 8)), 5 + engine.num_class
+
     def __init__(self, engine, B, H, W, flags=None):
         if H % 32 or W % 32:
             raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
@@ -341,6 +348,7 @@ class Engine:
         self.device = None
         self._sig = None
         self._plans = {}
+        self.lane_choices = {}        # Detector: (shape, eval) -> (lanes, stream pair, calibration ms), measured once per engine
         self.generation = 0
         # stream-K schedule of the 13x13 layers (+1.7 % at 416x416 bs=64): opt-in, because a tile split between two
         # workgroups is summed in a batch-position-dependent order (include/yv3.h, yv3_conv_desc.workspace)
@@ -366,18 +374,33 @@ class Engine:
         ``load_state_dict``, ``WeightManager`` loads and in-place ops on the parameter itself.  It does NOT see
         writes through ``param.data`` (``p.data.copy_()`` bumps the version counter of a temporary alias, not of
         ``p`` -- the reference's own loader idiom, darknet.py:275): after such edits call ``net.repack()``, or set
-        ``net.weight_check = "checksum"`` to add a device-side checksum of all parameters (one fused pass over the
-        248 MB of weights, ~0.1 ms per forward) to the signature."""
+        ``net.weight_check = "checksum"`` to add a device-side position-sensitive hash of all parameters (one pass over
+        the 248 MB of weights and one host sync per forward) to the signature."""
         ts = self._param_tensors()
         sig = tuple((t.data_ptr(), t._version) for t in ts)
         if getattr(self.net, "weight_check", "version") == "checksum" and ts and ts[0].is_cuda:
+            # position-sensitive integer hash of the parameters' BIT patterns: sum_i bits_i * (i mod 65521 + 1) in wrapping
+            # int64 per tensor, tensors combined with their index -- sees sign flips, swapped filters and swapped tensors
+            # (an L1 norm does not).  Costs one pass over the 248 MB of weights AND one host sync per forward (it defeats
+            # ``net.async_forward``): a debugging aid, not a default.
             with torch.no_grad():
-                norms = torch._foreach_norm([t.detach().float() for t in ts], 1)
-                sums = torch.stack(norms).double()
-                # position-weighted so that swapping two tensors' contents is seen as well
-                chk = float((sums * torch.arange(1, len(ts) + 1, device=sums.device, dtype=torch.float64)).sum())
+                parts = []
+                for t in ts:
+                    v = t.detach().contiguous().view(-1)
+                    v = (v.view(torch.int32) if v.dtype == torch.float32 else v.float().view(torch.int32)).to(torch.int64)
+                    w = self._iota(v.numel(), v.device)
+                    parts.append((v * w).sum())
+                tot = torch.stack(parts) * torch.arange(1, len(parts) + 1, device=parts[0].device, dtype=torch.int64)
+                chk = int(tot.sum().item())
             sig += (chk,)
         return sig
+
+    def _iota(self, n, device):
+        c = self.__dict__.setdefault("_iota_cache", {})
+        w = c.get((n, device))
+        if w is None:
+            w = c[(n, device)] = torch.arange(n, device=device, dtype=torch.int64) % 65521 + 1
+        return w
 
     def ensure_packed(self):
         sig = self._signature()
@@ -392,7 +415,17 @@ class Engine:
         self._plans = {}
         self.generation += 1          # holders of a Plan (Detector) must rebuild: descriptors point into `packed`
 
+    def invalidate(self):
+        """Forget the packed weights (the next `ensure_packed` re-packs from the current parameters and bumps
+        `generation`, so every holder of this engine -- a `Detector` the caller kept -- rebuilds its plans)."""
+        self.packed = None
+        self._sig = None
+        self._plans = {}
+
     # -- plans
+    def drop_plan(self, B, H, W):
+        self._plans.pop((B, H, W), None)
+
     def plan(self, B, H, W):
         key = (B, H, W)
         p = self._plans.get(key)
@@ -462,6 +495,9 @@ class Engine:
 
     OVERFLOW_MSG = ("an activation exceeded the fp16 range (|v| > 65504) and was saturated: math mode F32H2 cannot "
                     "represent this network/input; set net.math_mode = yolo_v3_amd.F32X3 (or F32) and rerun")
+    OVERFLOW_MSG_BF16 = ("the first layer of math mode BF16 runs on the fp16 matrix cores and needs |input| <= 4094 and "
+                         "|weight| <= 255 (csrc/conv0.hip); this input / these weights exceed that and were saturated: "
+                         "use net.math_mode = yolo_v3_amd.F32X3 (or F32)")
 
     def raise_if_overflowed(self, plan, flag_value):
         """Turn the kernels' sticky saturation flag into an error (and clear it)."""
@@ -472,12 +508,12 @@ class Engine:
             if flag_value & 2:
                 raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out "
                                     "(stream-K is opt-in: unset net.stream_k / YV3_SK and report)")
-            raise _ffi.Yv3Error(self.OVERFLOW_MSG)
+            raise _ffi.Yv3Error(self.OVERFLOW_MSG_BF16 if self.dtype == BF16 else self.OVERFLOW_MSG)
 
     def forward(self, x, dets=None):
         """x: [B,3,H,W] fp32 on the GPU -> detections [B, N, 5+C] (cx,cy,w,h,conf,cls...).
 
-        In F32H2 mode the kernels' saturation flag of THIS call is copied to pinned host memory behind the last
+        In F32H2 mode (and BF16, whose first layer splits its operands into fp16) the kernels' saturation flag of THIS call is copied to pinned host memory behind the last
         kernel and checked before returning (one event wait: the call then returns with the work complete, like the
         reference's forward followed by any use of its result), so no entry point built on it -- ``net(x)``,
         ``forward_cat``, ``detect(is_eval=True)``, ``predict_and_process`` -- can hand out saturated values.
@@ -489,13 +525,13 @@ class Engine:
             self.ensure_packed()
             B, _, H, W = x.shape
             plan = self.plan(B, H, W)
-            if self.dtype == F32H2 and plan.flags_event is not None and plan.flags_event.query():
+            if self.dtype in (F32H2, BF16) and plan.flags_event is not None and plan.flags_event.query():
                 self.raise_if_overflowed(plan, int(plan.flags_host[0]))
             if dets is None:
                 dets = torch.empty((B, plan.N, plan.attrib), device=x.device, dtype=torch.float32)
             self.run_convs(plan, x, dets)
             self.run_decode(plan, dets)
-            if self.dtype == F32H2:
+            if self.dtype in (F32H2, BF16):
                 plan.flags_host.copy_(plan.flags, non_blocking=True)
                 plan.flags_event = torch.cuda.Event()
                 plan.flags_event.record()

@@ -12,6 +12,8 @@
   strict ``>`` for both thresholds, zero-area boxes dropped (NaN self-IOU, utils.py:182);
 * unlike the reference (utils.py:227-233) the caller's tensor is never modified.
 """
+from collections import OrderedDict
+
 import torch
 
 from . import _ffi
@@ -26,20 +28,32 @@ def _as_gpu_f32(t, name):
 
 
 class PostProcessor:
-    """Reusable buffers for filter + NMS on ``[B, N, 5+C]`` detections (one per shape/device)."""
+    """Reusable buffers for filter + NMS on ``[B, N, 5+C]`` detections (one per shape/device).
 
-    def __init__(self, B, N, num_classes, device, max_cand=None, cap=None):
+    ``counts`` / ``out``: optional views into buffers owned by the caller -- ``counts = (cand [B], kept [B])`` int32,
+    ``out`` ``[B, cap, 7]`` fp32 -- so that several processors (the lanes of a `Detector`, each on its own stream)
+    fill disjoint image ranges of ONE result tensor and ONE counts buffer (a single D2H copy fetches all of it)."""
+
+    def __init__(self, B, N, num_classes, device, max_cand=None, cap=None, counts=None, out=None):
         self.B, self.N, self.C = B, N, num_classes
         self.device = torch.device(device)
         lib = _ffi.lib()
         self.max_cand = int(max_cand or N)
         self.cap = int(cap or self.max_cand)
         self.cand = torch.empty(lib.yv3_postproc_cand_bytes(B, self.max_cand, num_classes), dtype=torch.uint8, device=device)
-        # [0:B] candidate counts, [B:2B] kept counts -- one buffer so a single D2H copy fetches both
-        self.counts = torch.zeros(2 * B, dtype=torch.int32, device=device)
+        if counts is None:
+            # [0:B] candidate counts, [B:2B] kept counts -- one buffer so a single D2H copy fetches both
+            self.counts = torch.zeros(2 * B, dtype=torch.int32, device=device)
+            self.cand_counts, self.kept_counts = self.counts[:B], self.counts[B:]
+        else:
+            self.counts = None
+            self.cand_counts, self.kept_counts = counts
+            assert self.cand_counts.numel() == B and self.kept_counts.numel() == B
         self._ws = None
         self._ws_n = 0
-        self._out = None
+        self._out = out
+        if out is not None:
+            assert out.is_contiguous() and tuple(out.shape) == (B, self.cap, 7)
 
     def _workspace(self, max_n):
         lib = _ffi.lib()
@@ -51,7 +65,7 @@ class PostProcessor:
     def filter(self, dets, conf_thr, is_eval, prob=False):
         mode = (_ffi.PP_EVAL if is_eval else 0) | (_ffi.PP_PROB if prob else 0)
         _ffi.check(_ffi.lib().yv3_postproc_filter(dets.data_ptr(), self.B, self.N, self.C, float(conf_thr), mode,
-                                                  self.cand.data_ptr(), self.max_cand, self.counts.data_ptr(),
+                                                  self.cand.data_ptr(), self.max_cand, self.cand_counts.data_ptr(),
                                                   _ffi.stream_ptr()), "yv3_postproc_filter")
 
     def nms(self, dets, nms_thr, use_nms, max_n, cap):
@@ -60,8 +74,8 @@ class PostProcessor:
             self._out = torch.empty((self.B, cap, 7), dtype=torch.float32, device=self.device)
         out = self._out
         _ffi.check(_ffi.lib().yv3_postproc_nms(dets.data_ptr(), self.B, self.N, self.C, float(nms_thr), int(bool(use_nms)),
-                                               self.cand.data_ptr(), self.max_cand, self.counts.data_ptr(), max_n,
-                                               out.data_ptr(), out.shape[1], self.counts.data_ptr() + 4 * self.B,
+                                               self.cand.data_ptr(), self.max_cand, self.cand_counts.data_ptr(), max_n,
+                                               out.data_ptr(), out.shape[1], self.kept_counts.data_ptr(),
                                                ws.data_ptr(), ws.numel(), _ffi.stream_ptr()), "yv3_postproc_nms")
         return out
 
@@ -74,21 +88,46 @@ class PostProcessor:
 
     def to_list(self, out, counts_host):
         """Reference result convention from the device buffers + host copy of the counts."""
-        B = self.B
-        ncand, nkeep = counts_host[:B].tolist(), counts_host[B:].tolist()
-        if max(ncand) > self.max_cand:
-            raise _ffi.Yv3Error("candidate buffer overflow (%d > %d): raise max_cand" % (max(ncand), self.max_cand))
-        if max(nkeep) > out.shape[1]:
-            raise _ffi.Yv3Error("box buffer overflow (%d > %d): raise cap" % (max(nkeep), out.shape[1]))
-        if sum(ncand) == 0:
-            return []                                        # utils.py:248,251
-        kmax = max(nkeep)
-        host = out[:, :max(kmax, 1)].cpu()
-        return [host[b, :nkeep[b]].clone() if ncand[b] else torch.Tensor() for b in range(B)]
+        return boxes_to_list(out, counts_host, self.B, self.max_cand)
+
+
+def boxes_to_list(out, counts_host, B, max_cand):
+    """``[B,cap,7]`` device boxes + host counts (``[0:B]`` candidates, ``[B:2B]`` kept) -> the reference's result
+    convention (utils.py:148-202,248-251)."""
+    ncand, nkeep = counts_host[:B].tolist(), counts_host[B:2 * B].tolist()
+    if max(ncand) > max_cand:
+        raise _ffi.Yv3Error("candidate buffer overflow (%d > %d): raise max_cand" % (max(ncand), max_cand))
+    if max(nkeep) > out.shape[1]:
+        raise _ffi.Yv3Error("box buffer overflow (%d > %d): raise cap" % (max(nkeep), out.shape[1]))
+    if sum(ncand) == 0:
+        return []                                        # utils.py:248,251
+    kmax = max(nkeep)
+    host = out[:, :max(kmax, 1)].cpu()
+    return [host[b, :nkeep[b]].clone() if ncand[b] else torch.Tensor() for b in range(B)]
+
+
+_PP_CACHE = OrderedDict()       # (device, B, N, C, max_cand) -> PostProcessor; eval mode's key buffer is N*C*8 B per image
+_PP_CACHE_MAX = 2
+
+
+def _cached_postprocessor(B, N, num_classes, device, max_cand):
+    key = (str(device), B, N, num_classes, max_cand)
+    pp = _PP_CACHE.get(key)
+    if pp is None:
+        while len(_PP_CACHE) >= _PP_CACHE_MAX:
+            _PP_CACHE.popitem(last=False)
+        pp = _PP_CACHE[key] = PostProcessor(B, N, num_classes, device, max_cand=max_cand)
+    else:
+        _PP_CACHE.move_to_end(key)
+    return pp
 
 
 def postprocessing(detections, num_classes, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True):
-    """reference utils.py:226-258, on the GPU.  ``detections``: ``[B, N, 5+num_classes]``."""
+    """reference utils.py:226-258, on the GPU.  ``detections``: ``[B, N, 5+num_classes]``.
+
+    Buffers are sized from the actual candidate counts (one extra host sync between filter and NMS: eval mode can
+    produce up to N*C candidates per image); the processor -- in eval mode 8*N*C bytes of keys per image -- is
+    cached per shape, so repeated calls allocate nothing."""
     det = _as_gpu_f32(detections, "detections")
     if det.dim() != 3 or det.shape[2] < 5 + num_classes:
         raise _ffi.Yv3Error("detections must be [B, N, >=5+num_classes]")
@@ -99,7 +138,7 @@ def postprocessing(detections, num_classes, obj_conf_thr=0.5, nms_thr=0.4, is_ev
         return []
     with torch.cuda.device(det.device):
         max_cand = N * num_classes if is_eval else N
-        pp = PostProcessor(B, N, num_classes, det.device, max_cand=max_cand)
+        pp = _cached_postprocessor(B, N, num_classes, det.device, max_cand)
         pp.filter(det, obj_conf_thr, is_eval)
         ncand = pp.counts[:B].cpu()
         nmax = int(ncand.max())
