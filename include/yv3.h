@@ -60,7 +60,8 @@ const char* yv3_error_string(int code);
 
 /* OIHW fp32 [cout][cin][k][k]  ->  kernel layout for `dtype`; rows >= cout are 0.
  * YV3_F32: K-major [cout_pad][k][k][cin] fp32.  YV3_BF16 / YV3_F32_BF16X3: NP = 1 / 3 bf16 planes
- * pre-arranged tile by tile in the kernel's LDS image order; needs NP * cout_pad*k*k*cin * 2 bytes. */
+ * pre-arranged tile by tile in the kernel's LDS image order; needs NP * cout_pad*k*k*cin * 2 bytes.
+ * k = 1 or 3; k = 4 (plane dtypes only): the 4x4 Winograd-domain filters U = G g G^T of a 3x3 layer (yv3_conv_desc.w_wino). */
 int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin, int k,
                          int cout_pad, int dtype, void* stream);
 
@@ -162,6 +163,19 @@ typedef struct yv3_conv_desc {
        size, strides = those of the full tensors): the engine runs a layer whose tiles fill between one and two rounds of the
        chip as "exactly one round" + "the rest" (bit-identical results: the K order does not depend on the tiling). */
     long long x_plane_stride, x2_plane_stride, y_plane_stride;
+    /* Winograd F(2x2,3x3) path of the YV3_F32_F16X2 kernels (k = 3, stride 1, cin_up = 0, out_dtype == dtype; csrc/winograd.hip):
+       when w_wino is not NULL the layer runs as  V = B^T d B (one streaming launch: 4x4 input tiles at stride 2, transformed in
+       fp32, x 1/4, split hi/lo, written to wino_ws as [2][16][T][cin] fp16 planes, T = B*ceil(H/2)*ceil(W/2))  ->  sixteen
+       T x cout x cin GEMMs on the matrix cores, folded on the fly into the four outputs of every tile (Y = A^T M A), same
+       epilogue as the direct kernel: 2.25x fewer matrix instructions per output.  w_wino = the 4x4 transformed filters
+       U = G g G^T packed with yv3_pack_conv_weight(k = 4); alpha_wino = alpha with U's per-row power-of-two scale and the
+       x 4 of the input scaling folded in.  Results differ from the direct kernel by fp32 round-off only (per-layer error
+       ~2x the direct scheme's, tools/winograd_numerics.py).  wino_ws: scratch of yv3_wino_workspace_bytes(B,H,W,cin) bytes;
+       launches that may overlap must not share it. */
+    const void*  w_wino;
+    const float* alpha_wino;
+    void*        wino_ws;
+    size_t       wino_ws_bytes;
 } yv3_conv_desc;
 
 #define YV3_OPT_NO_PINGPONG 1u    /* fp16-plane 8-wave tiles: single-phase main loop instead of the two-group ping-pong */
@@ -171,6 +185,9 @@ typedef struct yv3_conv_desc {
 
 /* Size of yv3_conv_desc.workspace. */
 size_t yv3_conv_workspace_bytes(void);
+
+/* Size of yv3_conv_desc.wino_ws for a B x H x W x cin input (YV3_F32_F16X2). */
+size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin);
 
 /* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */
 int yv3_conv2d(const yv3_conv_desc* desc, void* stream);

@@ -58,7 +58,7 @@ def test_sharded_path_issues_one_collective(nccl_world1, sw1_stream):
     and the status word; the gathered payload unpacks to the detector's own boxes / counts bit for bit."""
     net = load_sw1_net(sw1_stream).cuda()
     x = torch.from_numpy(synth.images(4, 416, 9)).cuda()
-    sd = ydist.ShardedDetector(net, 4, 416, 416, cap=64, force_collective=True)
+    sd = ydist.ShardedDetector(net, 4, 416, 416, cap=256, force_collective=True)
     calls = []
     orig = dist.all_gather_into_tensor
     dist.all_gather_into_tensor = lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1]
@@ -67,9 +67,9 @@ def test_sharded_path_issues_one_collective(nccl_world1, sw1_stream):
         torch.cuda.synchronize()
     finally:
         dist.all_gather_into_tensor = orig
-    assert calls == [torch.Size([4, 65, 7])]
+    assert calls == [torch.Size([4, 257, 7])]
     boxes, meta = ydist.unpack_payload(gathered)
-    assert torch.equal(boxes, sd.det.boxes[:, :64]) and torch.equal(meta[:, 0], sd.det.counts[:4]) and torch.equal(meta[:, 1], sd.det.counts[4:])
+    assert torch.equal(boxes, sd.det.boxes[:, :256]) and torch.equal(meta[:, 0], sd.det.counts[:4]) and torch.equal(meta[:, 1], sd.det.counts[4:])
     assert int(meta[:, 2].max()) == 0
     res = sd.assemble(gathered, [(0, 4)])
     want = detect(net, x)

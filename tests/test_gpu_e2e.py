@@ -478,7 +478,8 @@ def test_eval_detect_fused_equals_two_phase(sw1_stream):
     for a, b in zip(fused, two_phase):
         assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b)
     # overflow of the fused buffers -> same answer through the fallback
-    from yolo_v3_amd import detect as dmod
+    import importlib
+    dmod = importlib.import_module("yolo_v3_amd.detect")
     key = [k for k in net._detectors if k[4] is True][0]
     det = net._detectors[key]
     det.max_cand_saved, det.max_cand = det.max_cand, 4        # pretend the candidate buffer was tiny

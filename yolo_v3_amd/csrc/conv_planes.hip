@@ -36,11 +36,18 @@ namespace {
 // waves stalling on LDS / DMA / barrier at the same time.
 // MINW = 2 (4-wave workgroups only): two workgroups per CU (<= 256 registers per wave); their barriers are independent, so
 // one workgroup's waves feed the matrix pipes while the other's wait for DMA / run their epilogue.
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false, int MINW = 1>
+// MTG (0 = whole wave tile): 32-row blocks per epilogue round (conv_planes_common.h) -- 128-row wave tiles use 2.
+// WINO (ping-pong kernels, NP = 2): Winograd F(2x2,3x3) GEMM stage (csrc/winograd.hip): the K loop walks the 16 transform
+// positions (Cin/32 chunks each, operand matrix xi * xi_stride into the V planes); at the end of a position the product
+// accumulators are folded into the tile's four outputs with the coefficients of A^T x A^T (0 / +-1: exact) and cleared.
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false, int MINW = 1, int MTG = 0,
+          bool WINO = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const ConvParamsP p) {
+    static_assert(!WINO || (PP && !SK && !K3 && !DUAL && !OUT_F32 && NP == 2), "Winograd stage: ping-pong fp16-plane kernel");
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile: WTM pixels x WTN channels
     constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int EMTG = MTG ? MTG : MT;
     constexpr int A_PLANE = BM * ROWB;                    // bytes
     constexpr int B_PLANE = BN * ROWB;
     constexpr int STAGE = NP * (A_PLANE + B_PLANE);
@@ -98,12 +105,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 aoff[q] = (((long long)b * p.H + ho * p.stride) * p.W + wo * p.stride) * p.Cin + sslot;
             }
         }
-        const int brow = n0 % p.tb + BROWS * wid + (lane >> 2);
-        btile = (long long)(n0 / p.tb) * p.nk;
+        const int n0w = n0 + BROWS * wid;                      // first weight row of this wave (a wave's rows never straddle a packed tile)
+        const int brow = n0w % p.tb + (lane >> 2);
+        btile = (long long)(n0w / p.tb) * p.nk;
         bin = brow * PBK + (lane & (SLOTS - 1)) * 8;
         const int cpt = p.Cin / PBK;                           // chunks per filter tap
-        const int tap = K3 ? k0 / cpt : 0;
-        kh = tap / 3; kw = tap - kh * 3; c0 = (k0 - tap * cpt) * PBK;
+        const int tap = (K3 || WINO) ? k0 / cpt : 0;
+        kh = WINO ? 0 : tap / 3; kw = tap - kh * 3; c0 = (k0 - tap * cpt) * PBK;      // (WINO: kw = transform position)
         tapinit = true;
     };
     if (!(PP && SK)) setup_tile(yv3_xcd_remap(blockIdx.x, gridDim.x), 0);
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                     ok = ok && (unsigned)(ahi[q] + kh) < (unsigned)p.H && (unsigned)(awi[q] + kw) < (unsigned)p.W;
                     off += ((long long)kh * p.W + kw) * p.Cin;
                 }
+                if (WINO) off += (long long)kw * p.xi_stride;
                 ap[q] = ok ? p.x + off : g_zero_page;
                 aps[q] = ok ? p.xs : 0;
                 ainc[q] = ok ? PBK : 0;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         }
         wbp = p.w + ((btile + kc) * NP) * (long long)(p.tb * PBK) + bin;
         c0 += PBK;
-        if (c0 == p.Cin) { c0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
+        if (c0 == p.Cin) { c0 = 0; if (WINO) ++kw; else if (++kw == 3) { kw = 0; ++kh; } }
     };
     auto dma_piece = [&](int idx) {
         if (idx < AQ * NP) {
@@ -172,6 +181,19 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x16 yac[WINO ? 4 : 1][NT][MT];          // WINO: the tile's four outputs Y[wi][wj] (index 2*wi + wj)
+    if constexpr (WINO) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) yac[o][i][j][e] = 0.f;
+    }
+    int wleft = WINO ? p.Cin / PBK : 0, wxi = 0;   // chunks left in the current transform position, its index
 
     const int l31 = lane & 31, lhi = lane >> 5;
     const int x_row = (wm * WTM + l31) * ROWB;                                  // pixel fragments (B operand)
@@ -303,6 +325,27 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WINO) {
+                    if (--wleft == 0) {                                            // end of a transform position: Y += (A^T x A^T)[.][xi] * M
+                        wleft = p.Cin / PBK;
+                        const int xr = wxi >> 2, xc = wxi & 3;
+                        ++wxi;
+                        const float r0 = xr < 3 ? 1.f : 0.f, r1 = xr == 0 ? 0.f : (xr == 1 ? 1.f : -1.f);
+                        const float q0 = xc < 3 ? 1.f : 0.f, q1 = xc == 0 ? 0.f : (xc == 1 ? 1.f : -1.f);
+                        const float sc[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+#pragma unroll
+                        for (int i = 0; i < NT; ++i)
+#pragma unroll
+                            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                                for (int e = 0; e < 16; ++e) {
+                                    const float mv = acc[i][j][e];
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) yac[o][i][j][e] = fmaf(mv, sc[o], yac[o][i][j][e]);
+                                    acc[i][j][e] = 0.f;
+                                }
+                    }
+                }
                 TL_MARK(tl_comp);
                 // both groups pass the same number of barriers; group 1 skips its last one so that group 0 can start the
                 // epilogue early -- except with SPLIT, where group 1 still reads fragments from LDS in its last segment
@@ -371,7 +414,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                     }
                 }
             }
-            epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false>(acc, p, lds, m0, n0, wid, lane);
+            if constexpr (WINO) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
+            } else epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false, EMTG>(acc, p, lds, m0, n0, wid, lane);
             TL_MARK(tl_epi);
 #ifdef YV3_TIMELINE
             ++tl_items; tl_chunks += k1 - k0;
@@ -485,16 +532,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         dbg[wid * 4 + 0] = (float)tl_wait; dbg[wid * 4 + 1] = (float)tl_bar; dbg[wid * 4 + 2] = (float)tl_body; dbg[wid * 4 + 3] = (float)tl_dma;
     }
 #endif
-    epilogue_store<NP, BM, BN, WM, WN, OUT_F32>(acc, p, lds, m0, n0, wid, lane);
+    epilogue_store<NP, BM, BN, WM, WN, OUT_F32, true, EMTG>(acc, p, lds, m0, n0, wid, lane);
 }
 
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1>
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1, int MTG = 0>
 int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_pp, hipStream_t s) {
     const int mtiles = (p.M + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
     const dim3 block(64 * WM * WN);
     const size_t pipe = (size_t)NSTAGE * NP * (BM + BN) * ROWB;
-    const size_t epi = (size_t)WN * BM * (BN / WN + 4) * 4;   // WM*WN waves x (BM/WM) rows x (BN/WN + 4) floats
+    const size_t epi = (size_t)WM * WN * (MTG ? MTG * 32 : BM / WM) * (BN / WN + 4) * 4;   // WM*WN waves x rows per round x (BN/WN + 4) floats
     const size_t lds = pipe > epi ? pipe : epi;
     const bool use_sk = true;                                      // stream-K persistent schedule iff the caller gave a workspace
     const int num_cu = yv3_num_cu();                               // of the CURRENT device; multiple of 8: equal workgroups per XCD
@@ -524,7 +571,7 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_
         if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
         if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
     } \
-    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, false, false, MINW>), grid, block, lds, s, q); } while (0)
+    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, false, false, MINW, MTG>), grid, block, lds, s, q); } while (0)
     if (out_f32) {
         if (k3 || dual) return YV3_ESHAPE;                   // fp32 outputs are the 1x1 head convs
         YV3_LAUNCH(false, false, true);
@@ -624,6 +671,34 @@ extern "C" int yv3_merge_planes(const void* in, float* out, long long n, int np,
 }
 
 int yv3_conv2d_planes_k3s1(const ConvParamsP* pp, int np, int npad, long long M, hipStream_t s);
+int yv3_wino_input_transform(const u16* x, long long xs, u16* v, int B, int H, int W, int C, hipStream_t s);
+
+// Winograd F(2x2,3x3) form of a 3x3 / stride-1 fp16-plane layer: input transform (winograd.hip) + the 16-position GEMM with the
+// output transform folded into the main loop.  `p` = the direct launch's parameters (x, res, y, strides, Cout, act, flags).
+static int launch_wino(const yv3_conv_desc* d, ConvParamsP p, hipStream_t s) {
+    const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
+    const long long T = (long long)d->B * th * tw;
+    if (T > 0x7fffffffLL || d->cout_pad % 128 || d->cin % 32) return YV3_ESHAPE;
+    if (!d->wino_ws || d->wino_ws_bytes < yv3_wino_workspace_bytes(d->B, d->H, d->W, d->cin)) return YV3_EWORKSPACE;
+    u16* v = (u16*)d->wino_ws;
+    int rc = yv3_wino_input_transform(p.x, p.xs, v, d->B, d->H, d->W, d->cin, s);
+    if (rc) return rc;
+    p.x = v; p.xs = 16 * T * d->cin; p.xi_stride = T * d->cin;
+    p.w = (const u16*)d->w_wino; p.alpha = d->alpha_wino;
+    p.wH = d->H; p.wW = d->W; p.wth = th; p.wtw = tw;
+    p.H = 1; p.W = (int)T; p.Ho = 1; p.Wo = (int)T; p.M = (int)T; p.stride = 1;
+    p.K = 16 * d->cin; p.nk = p.K / PBK;
+    p.tb = 128; p.ntiles = d->cout_pad / 128;
+    p.ws = nullptr; p.wsflags = nullptr; p.ws_bytes = 0;
+    constexpr int BM = 128, BN = 128, NS = 4;
+    const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
+    p.total = (int)grid.x;
+    const size_t pipe = (size_t)NS * 2 * (BM + BN) * ROWB, epi = (size_t)8 * 32 * (BN / 2 + 4) * 4;
+    hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, false, 1, 0, true>), grid, dim3(512),
+                       pipe > epi ? pipe : epi, s, p);
+    YV3_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" size_t yv3_conv_workspace_bytes(void) { return (size_t)YV3_SK_MAX_WG * (YV3_SK_PART_BYTES + sizeof(int)); }
 
@@ -673,6 +748,8 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
         if (rc != -100) return rc;
     }
+    if (d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino &&
+        d->x_plane_stride <= 0 && d->y_plane_stride <= 0) return launch_wino(d, p, s);
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
                                          np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, use_pp, s) : \
@@ -690,6 +767,10 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int force = (int)((d->options >> YV3_OPT_TILE_SHIFT) & 0xffu);
         if (np == 2 && force == 3) return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         if (np == 1 && force == 3) return launch_cfg<1, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
+        // 256x128 tile on FOUR waves (128x64 wave tiles: 6 fragment reads per 8 MFMAs instead of 4 per 4), two workgroups per CU
+        if (np == 1 && force == 5) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2>(p, k3, dual, out_f32, false, s);
+        // 256x256 tile on eight waves (128x64 wave tiles), one workgroup per CU, single-phase loop
+        if (np == 1 && force == 6 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, false, s); }
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         // short-K 1x1 layers (K <= 512: 8-16 chunks per tile, mostly prologue / epilogue): two independent 4-wave workgroups
         // per CU (128x128 tiles, 2-deep ring) hide each other's IO -- in the network at bs=64 the step gains 0.8 %
@@ -703,6 +784,14 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // images/s on one lane (two 4-wave workgroups per CU instead: 2953)
         // (6-deep ring, 147 KB: with 8 MFMAs per chunk and wave a DMA piece needs several chunk times to land; 3-deep 3690, 4-deep
         // 3830, 6-deep 3870 images/s at 608x608 bs=16)
+        // ... and from one tile per CU upwards the same 256x128 tile on FOUR waves (128x64 wave tiles: 6 fragment reads per 8 MFMAs
+        // instead of 4 per 4, half the DMA pieces per MFMA and wave), two independent workgroups per CU (72 KB of LDS each, <= 256
+        // registers), single-phase loop, epilogue in two rounds of 64 rows: same K order, bit-identical.  Same-box A/B
+        // (tools/tile_ab.py, profiles/r03_bf16_tile_ab*.log), 608x608 bs=16: 128->256 @76 665 -> 772 TFLOP/s, 256->512 @38 670 -> 811,
+        // 64->128 @152 559 -> 691, the stride-2 layers +11...18 %, 256->128 1x1 @76 +12 %; 416x416 bs=64: @52 663 -> 831, @26 825 -> 901,
+        // @13 702 -> 846.  Below one tile per CU (512->1024 @19 at bs=16: 184 tiles, 1x1 layers at 38 / 19) the 8-wave ping-pong
+        // tile wins by 7...30 % (twice the waves per tile).  A 256x256 / 8-wave tile (code 6) loses to both at these sizes.
+        if (np == 1 && force == 0 && blocks256 >= 256 && !out_f32) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2>(p, k3, dual, out_f32, false, s);
         if (np == 1 && use_pp && force == 0 && blocks256 >= big_min) return launch_cfg<1, 256, 128, 4, 2, 6>(p, k3, dual, out_f32, true, s);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);

@@ -26,6 +26,10 @@ struct ConvParamsP {
     int tb;                     // rows per packed weight tile
     int* flags;                 // optional: bit 0 <- an fp16-plane output was saturated
     int tune[4];                // tuning experiments (yv3_conv_desc.tune)
+    // Winograd launches (conv_planes_kernel<..., WINO>): rows of the GEMM are 2x2 output TILES; position xi's operand
+    // matrix starts xi * xi_stride elements into each plane of x; the epilogue maps tile rows back to pixels
+    long long xi_stride;
+    int wH, wW, wth, wtw;       // output height / width, tile grid
 };
 
 // stream-K workspace geometry (yv3_conv_workspace_bytes): one 512-thread workgroup's accumulators per CU + one flag
@@ -124,13 +128,39 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 
 
 // ---- epilogue shared by both kernels: acc[NT][MT] of the wave tile -> BN/activation -> LDS transpose ->
-// residual add -> output planes (or fp32).  `lds` must have NW * WTM * (WTN+4) * 4 bytes available.
-template <int NP, int BM, int BN, int WM, int WN, bool OUT_F32, bool SYNC = true>
+// residual add -> output planes (or fp32).  `lds` must have NW * (MTG*32) * (WTN+4) * 4 bytes available.
+// MTG: 32-row accumulator blocks transposed per round (default: the whole wave tile at once).  Wave tiles of 128
+// rows (two 4-wave workgroups per CU, 72 KB of LDS each) go through in rounds of MTG = 2 so that the per-wave
+// transpose tile fits, and fetch their residual rows round by round (registers).
+// WINO: row m of the tile is the 2x2 output tile m of a Winograd launch and `acc` holds its output (wi, wj): the row is
+// written to pixel (2 ty + wi, 2 tx + wj) (skipped beyond an odd picture's edge).
+template <int NP, int BM, int BN, int WM, int WN, bool OUT_F32, bool SYNC = true, int MTG = BM / WM / 32, bool WINO = false>
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], const ConvParamsP& p,
-                                               unsigned char* lds, int m0, int n0, int wid, int lane) {
+                                               unsigned char* lds, int m0, int n0, int wid, int lane, int wi = 0, int wj = 0) {
+    static_assert(!(WINO && OUT_F32), "Winograd launches write plane outputs");
+    auto rowpix = [&](int m) -> long long {          // pixel index of tile row m, -1: nothing to store
+        if constexpr (!WINO) return m < p.M ? (long long)m : -1;
+        else {
+            if (m >= p.M) return -1;
+            const int tt = p.wth * p.wtw;
+            const int b = m / tt;
+            const int rem = m - b * tt;
+            const int ty = rem / p.wtw, tx = rem - ty * p.wtw;
+            const int oy = 2 * ty + wi, ox = 2 * tx + wj;
+            return (oy < p.wH && ox < p.wW) ? ((long long)b * p.wH + oy) * p.wW + ox : -1;
+        }
+    };
+    if constexpr (WINO) {                            // the previous output's rows of this wave's LDS tile have been read
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int NG = MT / MTG;                      // rounds
+    constexpr int GR = MTG * 32;                      // pixel rows per round
+    static_assert(MT % MTG == 0, "rounds must divide the wave tile");
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     (void)NW;
@@ -142,7 +172,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     constexpr int EP = WTN + 4;                       // floats per tile row (+4: conflict-free ds_write_b128)
     constexpr int LPR = WTN / 8;                      // lanes per pixel row (8 channels each)
     constexpr int RPP = 64 / LPR;                     // pixel rows per pass
-    constexpr int NPASS = WTM / RPP;
+    constexpr int NPASS = GR / RPP;                   // passes per round
     // BN scale / shift of this lane's channels: ALL loads issued back to back, branch-free (clamped indices,
     // out-of-range lanes load valid garbage they never store) -- one L2 round trip instead of one per group.
     const bool has_alpha = p.alpha != nullptr;
@@ -165,24 +195,27 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
                 alv[i][g] = *reinterpret_cast<const f32x4*>(asrc + nn);
             }
         }
-    // Residual rows are fetched next, all passes at once, so that their HBM latency is paid once and overlaps
+    // Residual rows are fetched next, all passes of a round at once, so that their HBM latency is paid once and overlaps
     // the BN/activation + LDS transpose below (fetching them pass by pass serialises NPASS round trips).
     // NP = 3 would need 96 more registers than the 512-thread kernels have: it keeps the per-pass loads.
     constexpr bool PRE = !OUT_F32 && NP <= 2;
     u32x4 rres[PRE ? NPASS : 1][NP];
-    if constexpr (PRE) {
-        if (p.res && !(p.tune[3] & 2)) {
+    auto fetch_res = [&](int jg) {
+        if constexpr (PRE) {
+            if (p.res && !(p.tune[3] & 2)) {
 #pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int m = m0 + wm * WTM + ps * RPP + lane / LPR;
-                const int n = n0 + wn * WTN + (lane % LPR) * 8;
-                const long long o = (m < p.M && n < p.Cout) ? (long long)m * p.Cout + n : 0;      // clamped, unused if out of range
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const long long px = rowpix(m0 + wm * WTM + jg * GR + ps * RPP + lane / LPR);
+                    const int n = n0 + wn * WTN + (lane % LPR) * 8;
+                    const long long o = (px >= 0 && n < p.Cout) ? px * p.Cout + n : 0;      // clamped, unused if out of range
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) rres[ps][pl] = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
+                    for (int pl = 0; pl < NP; ++pl) rres[ps][pl] = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + o);
+                }
             }
         }
-    }
-    // (launch_cfg sizes the dynamic LDS as max(pipeline, NW * WTM * EP * 4))
+    };
+    fetch_res(0);
+    // (launch_cfg sizes the dynamic LDS as max(pipeline, NW * GR * EP * 4))
     if (!has_alpha) {                                 // wave-uniform: plain bias convs
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -191,39 +224,17 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     }
     const float slope = p.act == YV3_ACT_LEAKY ? 0.1f : 1.f;     // LeakyReLU(0.1) == max(t, 0.1 t); linear == max(t, t)
     if constexpr (SYNC) __syncthreads();              // every wave is done with the last stage
-    float* tile = reinterpret_cast<float*>(lds) + wid * (WTM * EP);
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = i * 32 + 8 * g + 4 * lhi;                 // channel inside the wave tile
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float t = fmaf(acc[i][j][4 * g + q], alv[i][g][q], bev[i][g][q]);
-                    v[q] = __builtin_fmaxf(t, slope * t);
-                }
-                *reinterpret_cast<f32x4*>(tile + (j * 32 + l31) * EP + nl) = v;
-            }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* tile = reinterpret_cast<float*>(lds) + wid * (GR * EP);
+    float amax = 0.f;                                 // running max |v| of what this lane stores (fp16 range check)
+    // fused decode state of a head conv (OUT_F32): this lane's channel is fixed over the rows
+    const int nd = n0 + wn * WTN + lane % WTN;
+    const int attrib = p.Cout / 3;
+    const int anc = (nd >= attrib) + (nd >= 2 * attrib);
+    const int attr = nd - anc * attrib;
+    const float an = OUT_F32 ? p.dec_an[(anc < 3 ? anc : 2) * 2 + (attr == 3 ? 1 : 0)] : 0.f;
+    int db = 0, dgy = 0, dgx = 0;
     if constexpr (OUT_F32) {
-        // fp32 logits of a head conv (cout = 255: rows are 1020 bytes, nothing is 16-byte aligned): consecutive lanes
-        // take consecutive channels, so every store instruction writes one or two contiguous row segments
-        static_assert(WTN <= 64 && 64 % WTN == 0, "one or more whole rows per store instruction");
-        constexpr int RPI = 64 / WTN;
-        float* yf = (float*)p.y;
-        // fused decode (yv3_decode's map, yololayer.py:31-59,97-105): this lane's channel is fixed over the rows
-        const int nd = n0 + wn * WTN + lane % WTN;
-        const int attrib = p.Cout / 3;
-        const int anc = (nd >= attrib) + (nd >= 2 * attrib);
-        const int attr = nd - anc * attrib;
-        const float an = p.dec_an[(anc < 3 ? anc : 2) * 2 + (attr == 3 ? 1 : 0)];
         // (image, grid y, grid x) of this lane's first row: two divisions once, then carried row by row
-        int db = 0, dgy = 0, dgx = 0;
         if (p.dec_out) {
             const int mf = m0 + wm * WTM + lane / WTN;
             const int HoWo = p.Ho * p.Wo;
@@ -231,40 +242,68 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
             const int pix = mf - db * HoWo;
             dgy = pix / p.Wo; dgx = pix - dgy * p.Wo;
         }
-#pragma unroll 8
-        for (int r0 = 0; r0 < WTM; r0 += RPI) {
-            const int r = r0 + lane / WTN, c = lane % WTN;
-            const int m = m0 + wm * WTM + r, n = n0 + wn * WTN + c;
-            if (m < p.M && n < p.Cout) {
-                const float t = tile[r * EP + c];
-                if (yf) yf[(long long)m * p.Cout + n] = t;
-                if (p.dec_out)
-                    p.dec_out[(long long)db * p.dec_bs + (long long)(dgy * p.Wo + dgx) * p.Cout + n] =
-                        yv3_decode_value(t, attr, an, (float)dgx, (float)dgy, p.dec_stride);
-            }
-            dgx += RPI;                                             // RPI <= 2 < Wo: at most one wrap per step
-            if (dgx >= p.Wo) { dgx -= p.Wo; if (++dgy == p.Ho) { dgy = 0; ++db; } }
-        }
-        return;
     }
-    float amax = 0.f;                                 // running max |v| of what this lane stores (fp16 range check)
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int r = ps * RPP + lane / LPR;
-        const int cg = (lane % LPR) * 8;
-        const int m = m0 + wm * WTM + r;
-        const int n = n0 + wn * WTN + cg;
-        if (m >= p.M || n >= p.Cout) continue;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const long long o = (long long)m * p.Cout + n;
-        if (OUT_F32) {
-            float* yo = (float*)p.y + o;
+    for (int jg = 0; jg < NG; ++jg) {
+        if (jg > 0) {                                 // the previous round's rows have been read by every lane
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            fetch_res(jg);
+        }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (n + q < p.Cout) yo[q] = v[q];
-        } else {
+        for (int jj = 0; jj < MTG; ++jj)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int j = jg * MTG + jj;
+                    const int nl = i * 32 + 8 * g + 4 * lhi;                 // channel inside the wave tile
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = fmaf(acc[i][j][4 * g + q], alv[i][g][q], bev[i][g][q]);
+                        v[q] = __builtin_fmaxf(t, slope * t);
+                    }
+                    *reinterpret_cast<f32x4*>(tile + (jj * 32 + l31) * EP + nl) = v;
+                }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (OUT_F32) {
+            // fp32 logits of a head conv (cout = 255: rows are 1020 bytes, nothing is 16-byte aligned): consecutive lanes
+            // take consecutive channels, so every store instruction writes one or two contiguous row segments
+            static_assert(WTN <= 64 && 64 % WTN == 0, "one or more whole rows per store instruction");
+            constexpr int RPI = 64 / WTN;
+            float* yf = (float*)p.y;
+            // fused decode (yv3_decode's map, yololayer.py:31-59,97-105)
+#pragma unroll 8
+            for (int r0 = 0; r0 < GR; r0 += RPI) {
+                const int r = r0 + lane / WTN, c = lane % WTN;
+                const int m = m0 + wm * WTM + jg * GR + r, n = n0 + wn * WTN + c;
+                if (m < p.M && n < p.Cout) {
+                    const float t = tile[r * EP + c];
+                    if (yf) yf[(long long)m * p.Cout + n] = t;
+                    if (p.dec_out)
+                        p.dec_out[(long long)db * p.dec_bs + (long long)(dgy * p.Wo + dgx) * p.Cout + n] =
+                            yv3_decode_value(t, attr, an, (float)dgx, (float)dgy, p.dec_stride);
+                }
+                dgx += RPI;                                             // RPI <= 2 < Wo: at most one wrap per step
+                if (dgx >= p.Wo) { dgx -= p.Wo; if (++dgy == p.Ho) { dgy = 0; ++db; } }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + lane / LPR;
+            const int cg = (lane % LPR) * 8;
+            const long long px = rowpix(m0 + wm * WTM + jg * GR + r);
+            const int n = n0 + wn * WTN + cg;
+            if (px < 0 || n >= p.Cout) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const long long o = px * p.Cout + n;
             if (p.res) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {       // planes sum back to the exact fp32 value
