@@ -17,7 +17,7 @@ from oracle import oracle_cpu as oc
 from yolo_v3_amd import _ffi, arch, synth, engine
 from yolo_v3_amd import YoloLayer, postprocessing, iou_vectorized, bbox_iou, bbox_cxcywh_to_x1y1x2y2
 from yolo_v3_amd.darknet import conv_bn_relu, res_layer, UpsampleGroup, PreDetectionConvGroup
-from tests.helpers import assert_close_rel, check_result_convention
+from tests.helpers import assert_close_rel, check_result_convention, rel_err
 
 pytestmark = pytest.mark.gpu
 ANCHOR_PAIRS = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)]
@@ -530,3 +530,43 @@ def test_fused_res64_equals_two_launches_bitwise(B, H, W):
     assert outs[0].shape == (2, B, H // 2, W // 2, 64)
     assert torch.equal(outs[0], outs[1]), "%d elements differ" % int((outs[0] != outs[1]).sum())
     assert torch.equal(dets[0], dets[1])
+
+
+def _run_wino(m, x_nchw, residual_nchw=None):
+    """conv_bn_relu `m` (3x3, stride 1, on the GPU) through the Winograd F(2x2,3x3) form of the fp16-plane kernel."""
+    mode = _ffi.F32H2
+    sp = m._spec()
+    pc = engine.pack_conv(m, sp, mode, winograd=True)
+    assert pc.w_wino is not None
+    B, _, H, W = x_nchw.shape
+    x = engine.to_planes(x_nchw.cuda().permute(0, 2, 3, 1).contiguous(), mode)
+    y = engine.alloc_act(B, H, W, sp.cout, mode, "cuda")
+    y.fill_(float("nan"))
+    r = engine.to_planes(residual_nchw.cuda().permute(0, 2, 3, 1).contiguous(), mode) if residual_nchw is not None else None
+    ws = torch.empty(_ffi.lib().yv3_wino_workspace_bytes(B, H, W, sp.cin), dtype=torch.uint8, device="cuda")
+    d = engine.make_desc(pc, x, y, B, H, W, r, dtype=mode, wino_ws=ws)
+    assert d.w_wino
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    return engine.from_planes(y, mode).permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W,res", [(256, 512, 3, 26, 26, True), (512, 1024, 5, 13, 13, True), (256, 512, 2, 38, 38, False),
+                                                (512, 1024, 2, 19, 19, True), (256, 128, 1, 6, 10, False), (256, 256, 2, 7, 5, True)])
+def test_winograd_conv_vs_fp64(cin, cout, B, H, W, res):
+    """Winograd F(2x2,3x3) form of conv_bn_relu(3x3, s1) (+ residual) in the fp16 hi+lo plane mode: even and ODD pictures
+    (13x13, 19x19, 7x5: the last tile row / column hangs over the edge), M tails, every output written exactly once.
+    Against fp64: 2e-5 * max(1,|ref|) (the direct kernels' bar; measured ~2x the direct scheme's error,
+    tools/winograd_numerics.py), and within 2e-5 of the direct fp16-plane kernel."""
+    m = _rand_cbr(cin, cout, 3, 1, seed=cin + cout + H)
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.rand(B, cin, H, W, generator=g) * 2 - 0.5
+    r = (torch.rand(B, cout, H, W, generator=g) - 0.5) if res else None
+    ref = _ref_cbr(m, x) + (r.double() if res else 0)
+    mc = m.cuda()
+    out = _run_wino(mc, x, r)
+    assert torch.isfinite(out).all(), "an output element was not written"
+    e = assert_close_rel(out, ref, 2e-5, "winograd conv %s" % ((cin, cout, H, W),))
+    direct = _run_mode(mc, x, _ffi.F32H2, r)
+    e_d = float(rel_err(direct, ref).max())
+    print("winograd %s: err vs fp64 %.3g (direct kernel %.3g)" % ((cin, cout, B, H, W), e, e_d))
+    assert_close_rel(out, direct, 2e-5, "winograd vs direct")

@@ -61,10 +61,11 @@ def _ptr(t):
 
 class PackedConv:
     """Device-side parameters of one convolution in kernel layout."""
-    __slots__ = ("spec", "w", "alpha", "beta", "cout_pad")
+    __slots__ = ("spec", "w", "alpha", "beta", "cout_pad", "w_wino", "alpha_wino")
 
-    def __init__(self, spec, w, alpha, beta, cout_pad):
+    def __init__(self, spec, w, alpha, beta, cout_pad, w_wino=None, alpha_wino=None):
         self.spec, self.w, self.alpha, self.beta, self.cout_pad = spec, w, alpha, beta, cout_pad
+        self.w_wino, self.alpha_wino = w_wino, alpha_wino      # Winograd-domain filters of an eligible 3x3 layer (F32H2)
 
 
 def conv_params(module):
@@ -74,7 +75,33 @@ def conv_params(module):
     return module.conv.weight, module.bn, None
 
 
-def pack_conv(module, spec, dtype):
+WINO_MIN_CIN = int(os.environ.get("YV3_WINO_MIN_CIN", "256") or 256)     # Winograd F(2x2,3x3) for 3x3 / stride-1 layers with at least this many input channels (26x26 and 13x13 at
+                       # 416x416): below, the transformed input (16 B per input element through HBM) costs more than the MFMAs saved
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def wino_eligible(spec, dtype):
+    return dtype == F32H2 and spec.k == 3 and spec.stride == 1 and spec.cin >= WINO_MIN_CIN and spec.bn
+
+
+def pack_wino(weight_f32, alpha_bn, spec, cout_pad):
+    """U = G g G^T (fp64 -> fp32) of every 3x3 filter, per-output-channel power-of-two scaling as for the direct weights,
+    packed as a 16-tap ("k = 4") filter bank; alpha_wino = alpha * 2^-e * 4 (the input transform carries a factor 1/4)."""
+    lib = _ffi.lib()
+    dev = weight_f32.device
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=dev)
+    U = torch.einsum("ij,ocjk,lk->ocil", G, weight_f32.double(), G).float().contiguous()            # [cout, cin, 4, 4]
+    umax = U.abs().amax(dim=(1, 2, 3))
+    e = torch.where(umax > 0, -torch.floor(torch.log2(umax.clamp(min=1e-38))), torch.zeros_like(umax)).clamp(-100.0, 100.0)
+    U = (U * torch.exp2(e).view(-1, 1, 1, 1)).contiguous()
+    alpha_w = (alpha_bn * torch.exp2(-e) * 4.0).contiguous()
+    wp = torch.empty(2 * cout_pad * 16 * spec.cin, device=dev, dtype=torch.float16)
+    _ffi.check(lib.yv3_pack_conv_weight(U.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, 4, cout_pad, F32H2, _ffi.stream_ptr()),
+               "yv3_pack_conv_weight(k=4)")
+    return wp, alpha_w
+
+
+def pack_conv(module, spec, dtype, winograd=False):
     """Pack one conv (+BN) for the HIP kernels.  Parameters must already be on the GPU."""
     lib = _ffi.lib()
     weight, bn, bias = conv_params(module)
@@ -92,6 +119,7 @@ def pack_conv(module, spec, dtype):
     else:
         alpha = None
         beta = bias.detach().float().contiguous().clone()
+    w_orig, alpha_bn = w32, alpha
     if dtype == F32H2 and spec.cin != 3:
         # fp16 planes keep a relative precision of 2^-22 only while the `lo` part is a normal fp16 number, i.e. for
         # |w| >= 2^-3 after scaling: bring EVERY OUTPUT CHANNEL's weights to max|w_row| in [1,2) with its own exact
@@ -112,6 +140,9 @@ def pack_conv(module, spec, dtype):
     wp = torch.empty(max(1, PLANES[dtype]) * nw, device=dev, dtype=_TORCH_DTYPE[dtype])
     _ffi.check(lib.yv3_pack_conv_weight(w32.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, spec.k,
                                         cout_pad, dtype, s), "yv3_pack_conv_weight")
+    if winograd and wino_eligible(spec, dtype):
+        ww, aw = pack_wino(w_orig, alpha_bn, spec, cout_pad)
+        return PackedConv(spec, wp, alpha, beta, cout_pad, ww, aw)
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
 
@@ -151,7 +182,7 @@ def batch_split(B, ho, wo, cout_pad, ncu):
 
 
 def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None,
-              batch=None):
+              batch=None, wino_ws=None):
     """`batch` = (b0, nb): the descriptor covers images b0 .. b0+nb-1 of the [NP][B,...] plane tensors (plane dtypes only)."""
     sp = pc.spec
     d = ConvDesc()
@@ -170,6 +201,9 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
     d.flags = _ptr(flags)
     d.workspace = _ptr(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    if wino_ws is not None and pc.w_wino is not None and batch is None and dtype == F32H2 and (out_dtype is None or out_dtype == dtype):
+        d.w_wino, d.alpha_wino = _ptr(pc.w_wino), _ptr(pc.alpha_wino)
+        d.wino_ws, d.wino_ws_bytes = _ptr(wino_ws), wino_ws.numel() * wino_ws.element_size()
     if batch is not None:
         b0, nb = batch
         ho, wo = out_hw(H, W, sp.k, sp.stride)
@@ -220,6 +254,14 @@ class Plan:
         self.workspace = (torch.zeros(_ffi.lib().yv3_conv_workspace_bytes(), device=dev, dtype=torch.uint8)
                           if (dt == F32H2 and engine.stream_k) else None)
         self.layer_out = {}  # conv name -> (buffer, (h, w, c)) for bring-up / per-layer parity tests
+        # Winograd scratch (the transformed input of ONE layer at a time; launches of a plan are stream-ordered): sized for
+        # the largest eligible layer of this plan
+        self.wino_ws = None
+        if engine.winograd and dt == F32H2:
+            wsb = _ffi.lib().yv3_wino_workspace_bytes
+            # eligible layers (cin >= 256) read 256 channels at H/16 or 512 at H/32
+            need = max(wsb(B, H // 16, W // 16, 256), wsb(B, H // 32, W // 32, 512))
+            self.wino_ws = torch.empty(need, device=dev, dtype=torch.uint8)
 
         def buf(h, w, c, dtype=dt):
             t = alloc_act(B, h, w, c, dtype, dev)
@@ -251,7 +293,8 @@ class Plan:
             if engine.batch_split and dt == F32H2 and pc.spec.k == 3 and not head and self.workspace is None:
                 split = batch_split(B, ho, wo, pc.cout_pad, ncu)
             for part in ([None] if split is None else [(0, split[0]), (split[0], split[1])]):
-                descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace, batch=part))
+                descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace, batch=part,
+                                       wino_ws=self.wino_ws))
                 self.desc_spec.append(i)
             if y is not None:
                 self.layer_out[pc.spec.name] = y
@@ -358,6 +401,8 @@ class Engine:
         self.fuse_res64 = bool(getattr(net, "fuse_res64", os.environ.get("YV3_NO_FUSED_RES64") is None))
         # opt-in (measured null end to end, see batch_split): 13x13 layers as "one full round" + "the rest"
         self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_BATCH_SPLIT") == "1"))
+        # Winograd F(2x2,3x3) for the 3x3 stride-1 layers with >= 256 input channels (fp16-plane mode; csrc/winograd.hip)
+        self.winograd = bool(getattr(net, "winograd", os.environ.get("YV3_WINO", "0") == "1"))
 
     # -- weights
     def _param_tensors(self):
@@ -410,7 +455,7 @@ class Engine:
         _ffi.require_cuda(first, "YoloNet parameters (call net.cuda() first)")
         self.device = first.device
         with torch.cuda.device(self.device):
-            self.packed = [pack_conv(self.net.get_submodule(sp.name), sp, self.dtype) for sp in self.specs]
+            self.packed = [pack_conv(self.net.get_submodule(sp.name), sp, self.dtype, self.winograd) for sp in self.specs]
         self._sig = sig
         self._plans = {}
         self.generation += 1          # holders of a Plan (Detector) must rebuild: descriptors point into `packed`
