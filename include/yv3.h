@@ -170,8 +170,13 @@ typedef struct yv3_conv_desc {
        epilogue as the direct kernel: 2.25x fewer matrix instructions per output.  w_wino = the 4x4 transformed filters
        U = G g G^T packed with yv3_pack_conv_weight(k = 4); alpha_wino = alpha with U's per-row power-of-two scale and the
        x 4 of the input scaling folded in.  Results differ from the direct kernel by fp32 round-off only (per-layer error
-       ~2x the direct scheme's, tools/winograd_numerics.py).  wino_ws: scratch of yv3_wino_workspace_bytes(B,H,W,cin) bytes;
-       launches that may overlap must not share it. */
+       ~2x the direct scheme's, tools/winograd_numerics.py).  wino_ws: scratch of yv3_wino_workspace_bytes(B,H,W,cin) bytes,
+       ZERO-FILLED once by the caller and then left alone (its tail holds the hand-over flags of the even schedule);
+       launches that may overlap must not share it.  The library takes this path when the layer's 128x128 Winograd tiles fill
+       0.55 ... 1.05 rounds of the chip's CUs (measured crossovers; YV3_OPT_WINO_ALWAYS: whenever w_wino is set) and the direct
+       kernel otherwise -- the choice depends on B, so the same image may be computed by either form at different batch sizes
+       (both within fp32 round-off of the exact result, not bit-identical to each other).  YV3_OPT_WINO_EVEN: stream-K schedule
+       over transform positions (one persistent workgroup per CU; a split tile is summed head + tail). */
     const void*  w_wino;
     const float* alpha_wino;
     void*        wino_ws;
@@ -180,6 +185,8 @@ typedef struct yv3_conv_desc {
 
 #define YV3_OPT_NO_PINGPONG 1u    /* fp16-plane 8-wave tiles: single-phase main loop instead of the two-group ping-pong */
 #define YV3_OPT_K3S1        2u    /* 3x3 stride-1 plane convs: the kw-tap-reuse kernel (conv_planes_k3s1.hip)          */
+#define YV3_OPT_WINO_EVEN   4u    /* Winograd stage: even (stream-K over transform positions) schedule instead of one tile per workgroup */
+#define YV3_OPT_WINO_ALWAYS 8u    /* Winograd stage whenever w_wino is set, whatever the tile count                                     */
 #define YV3_OPT_TILE_SHIFT  8     /* bits 8..15: force a tile configuration of the fp16-plane kernels (0 = automatic):
                                      1 = 256x128 / 8 waves, 2 = 128x128 / 8 waves, 3 = 128x128 / 4 waves, two workgroups per CU */
 

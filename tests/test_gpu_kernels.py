@@ -532,7 +532,7 @@ def test_fused_res64_equals_two_launches_bitwise(B, H, W):
     assert torch.equal(dets[0], dets[1])
 
 
-def _run_wino(m, x_nchw, residual_nchw=None):
+def _run_wino(m, x_nchw, residual_nchw=None, even=False):
     """conv_bn_relu `m` (3x3, stride 1, on the GPU) through the Winograd F(2x2,3x3) form of the fp16-plane kernel."""
     mode = _ffi.F32H2
     sp = m._spec()
@@ -543,15 +543,21 @@ def _run_wino(m, x_nchw, residual_nchw=None):
     y = engine.alloc_act(B, H, W, sp.cout, mode, "cuda")
     y.fill_(float("nan"))
     r = engine.to_planes(residual_nchw.cuda().permute(0, 2, 3, 1).contiguous(), mode) if residual_nchw is not None else None
-    ws = torch.empty(_ffi.lib().yv3_wino_workspace_bytes(B, H, W, sp.cin), dtype=torch.uint8, device="cuda")
-    d = engine.make_desc(pc, x, y, B, H, W, r, dtype=mode, wino_ws=ws)
+    ws = torch.zeros(_ffi.lib().yv3_wino_workspace_bytes(B, H, W, sp.cin), dtype=torch.uint8, device="cuda")
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d = engine.make_desc(pc, x, y, B, H, W, r, dtype=mode, wino_ws=ws, flags=flags)
     assert d.w_wino
-    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    d.options |= _ffi.OPT_WINO_ALWAYS | (_ffi.OPT_WINO_EVEN if even else 0)
+    for _ in range(2):                                   # twice: the hand-over flags of the even schedule must be left reset
+        y.fill_(float("nan"))
+        _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    assert int(flags.item()) == 0, "kernel status word %d" % int(flags.item())
     return engine.from_planes(y, mode).permute(0, 3, 1, 2).cpu()
 
 
 @pytest.mark.parametrize("cin,cout,B,H,W,res", [(256, 512, 3, 26, 26, True), (512, 1024, 5, 13, 13, True), (256, 512, 2, 38, 38, False),
-                                                (512, 1024, 2, 19, 19, True), (256, 128, 1, 6, 10, False), (256, 256, 2, 7, 5, True)])
+                                                (512, 1024, 2, 19, 19, True), (256, 128, 1, 6, 10, False), (256, 256, 2, 7, 5, True),
+                                                (256, 512, 24, 26, 26, True), (512, 1024, 40, 13, 13, True)])
 def test_winograd_conv_vs_fp64(cin, cout, B, H, W, res):
     """Winograd F(2x2,3x3) form of conv_bn_relu(3x3, s1) (+ residual) in the fp16 hi+lo plane mode: even and ODD pictures
     (13x13, 19x19, 7x5: the last tile row / column hangs over the edge), M tails, every output written exactly once.
@@ -568,5 +574,11 @@ def test_winograd_conv_vs_fp64(cin, cout, B, H, W, res):
     e = assert_close_rel(out, ref, 2e-5, "winograd conv %s" % ((cin, cout, H, W),))
     direct = _run_mode(mc, x, _ffi.F32H2, r)
     e_d = float(rel_err(direct, ref).max())
-    print("winograd %s: err vs fp64 %.3g (direct kernel %.3g)" % ((cin, cout, B, H, W), e, e_d))
+    # the opt-in even schedule (YV3_OPT_WINO_EVEN: tiles split between positions, partial outputs handed over in L2): same
+    # products, another summation order
+    ev = _run_wino(mc, x, r, even=True)
+    assert torch.isfinite(ev).all()
+    e_t = assert_close_rel(ev, ref, 2e-5, "winograd (even schedule) %s" % ((cin, cout, H, W),))
+    print("winograd %s: err vs fp64 %.3g tile schedule, %.3g even schedule (direct kernel %.3g)" % ((cin, cout, B, H, W), e, e_t, e_d))
     assert_close_rel(out, direct, 2e-5, "winograd vs direct")
+    assert_close_rel(out, ev, 1e-5, "even vs tile schedule")

@@ -19,16 +19,19 @@ for name in sys.argv[1:] or ["c26", "c13"]:
     xf = torch.rand(B, H, H, cin, device="cuda") - 0.5
     x = engine.to_planes(xf, dt)
     r = engine.to_planes(torch.rand(B, H, H, cout, device="cuda") - 0.5, dt)
-    ws = torch.empty(lib.yv3_wino_workspace_bytes(B, H, H, cin), dtype=torch.uint8, device="cuda")
-    ys = [engine.alloc_act(B, H, H, cout, dt, "cuda") for _ in range(2)]
-    descs = [engine.make_desc(pc, x, ys[0], B, H, H, r, dtype=dt), engine.make_desc(pc, x, ys[1], B, H, H, r, dtype=dt, wino_ws=ws)]
+    ws = torch.zeros(lib.yv3_wino_workspace_bytes(B, H, H, cin), dtype=torch.uint8, device="cuda")
+    ys = [engine.alloc_act(B, H, H, cout, dt, "cuda") for _ in range(3)]
+    descs = [engine.make_desc(pc, x, ys[0], B, H, H, r, dtype=dt), engine.make_desc(pc, x, ys[1], B, H, H, r, dtype=dt, wino_ws=ws),
+             engine.make_desc(pc, x, ys[2], B, H, H, r, dtype=dt, wino_ws=ws)]
+    descs[1].options |= _ffi.OPT_WINO_ALWAYS | _ffi.OPT_WINO_EVEN
+    descs[2].options |= _ffi.OPT_WINO_ALWAYS
     for d in descs:
         for _ in range(3):
             _ffi.check(lib.yv3_conv2d(d, st))
     torch.cuda.synchronize()
     a, b = engine.from_planes(ys[0], dt), engine.from_planes(ys[1], dt)
     err = ((a - b).abs() / a.abs().clamp(min=1.0)).max().item()
-    best = [1e9, 1e9]
+    best = [1e9, 1e9, 1e9]
     for rep in range(3):
         for i, d in enumerate(descs):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,5 +41,5 @@ for name in sys.argv[1:] or ["c26", "c13"]:
             e1.record(); torch.cuda.synchronize()
             best[i] = min(best[i], e0.elapsed_time(e1) / iters)
     fl = 2.0 * B * H * H * cout * cin * 9
-    print("%-4s B=%d %dx%d %d->%d : direct %.4f ms (%.0f alg TF)   winograd %.4f ms (%.0f alg TF)   x%.2f   max|d| %.3g"
-          % (name, B, H, H, cin, cout, best[0], fl / best[0] / 1e9, best[1], fl / best[1] / 1e9, best[0] / best[1], err)); sys.stdout.flush()
+    print("%-4s B=%d %dx%d %d->%d : direct %.4f ms (%.0f alg TF)   winograd even schedule %.4f ms (%.0f alg TF) x%.2f   tile schedule %.4f ms x%.2f   max|d| %.3g"
+          % (name, B, H, H, cin, cout, best[0], fl / best[0] / 1e9, best[1], fl / best[1] / 1e9, best[0] / best[1], best[2], best[0] / best[2], err)); sys.stdout.flush()

@@ -43,7 +43,7 @@ namespace {
 template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false, int MINW = 1, int MTG = 0,
           bool WINO = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const ConvParamsP p) {
-    static_assert(!WINO || (PP && !SK && !K3 && !DUAL && !OUT_F32 && NP == 2), "Winograd stage: ping-pong fp16-plane kernel");
+    static_assert(!WINO || (PP && !K3 && !DUAL && !OUT_F32 && NP == 2), "Winograd stage: ping-pong fp16-plane kernel");
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile: WTM pixels x WTN channels
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -243,24 +243,41 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         // [0, k1) of another, whose tail the next workgroup of the same XCD dumped at ITS start, long ago: head + tail
         // are added in that fixed order and the epilogue runs once.  Ranges are >= nk chunks (host guarantees tiles >=
         // workgroups), so a tile is never split three ways.
-        int it = 0, it_end = p.nk, tile_base = 0;
+        // The schedulable unit of the stream-K ranges is one K chunk -- or (WINO) one whole transform position (UC chunks): a
+        // Winograd tile is only split between positions, where the product accumulators are zero and a part is the four
+        // partial outputs.
+        const int UC = WINO ? p.Cin / PBK : 1;                                    // chunks per unit
+        const int UN = WINO ? 16 : p.nk;                                          // units per tile
+        int it = 0, it_end = UN, tile_base = 0;
         const int jb = blockIdx.x >> 3, nj = gridDim.x >> 3;                     // (SK) this workgroup's slot in its XCD
-        long long tx = 0;                                                        // (SK) chunk iterations of this XCD
+        long long tx = 0;                                                        // (SK) unit iterations of this XCD
         if constexpr (SK) {
             const int xcd = blockIdx.x & 7;
             const int t0 = (int)((long long)xcd * p.total / 8), t1 = (int)((long long)(xcd + 1) * p.total / 8);
-            tx = (long long)(t1 - t0) * p.nk;
+            tx = (long long)(t1 - t0) * UN;
             it = (int)(tx * jb / nj); it_end = (int)(tx * (jb + 1) / nj); tile_base = t0;
         }
         bool first_item = true;
         while (it < it_end) {
-            int k0 = 0, k1 = p.nk;
+            int u0 = 0, u1 = UN;
             if constexpr (SK) {
-                const int tl = it / p.nk;
-                k0 = it - tl * p.nk;
-                k1 = it_end - it < p.nk - k0 ? k0 + (it_end - it) : p.nk;
-                setup_tile(tile_base + tl, k0);
+                const int tl = it / UN;
+                u0 = it - tl * UN;
+                u1 = it_end - it < UN - u0 ? u0 + (it_end - it) : UN;
+                setup_tile(tile_base + tl, u0 * UC);
                 if (!first_item) __syncthreads();                                 // the previous item's epilogue tiles are dead
+            }
+            const int k0 = u0 * UC, k1 = u1 * UC;
+            if constexpr (WINO) {
+                wleft = UC; wxi = u0;
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) yac[o][i][j][e] = 0.f;
             }
 #pragma unroll
             for (int i = 0; i < NT; ++i)
@@ -359,17 +376,22 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
             // tiles are per wave)
             if (SPLIT && grp == 0) __builtin_amdgcn_s_barrier();
             if constexpr (SK) {
-                constexpr int PART = NT * MT * 16 * 64;                          // floats of one wave's accumulators
-                if (k0 > 0) {                                                    // tail / middle part: hand the accumulators over
+                constexpr int NO = WINO ? 4 : 1;                                 // accumulator sets of a part (WINO: the four outputs)
+                constexpr int PART = NO * NT * MT * 16 * 64;                     // floats of one wave's part
+                if (u0 > 0) {                                                    // tail / middle part: hand the accumulators over
                     float* w = p.ws + ((size_t)blockIdx.x * NW + wid) * PART + lane * 4;
 #pragma unroll
-                    for (int i = 0; i < NT; ++i)
+                    for (int o = 0; o < NO; ++o)
 #pragma unroll
-                        for (int j = 0; j < MT; ++j)
+                        for (int i = 0; i < NT; ++i)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                *reinterpret_cast<f32x4*>(w + ((i * MT + j) * 4 + g) * 256) =
-                                    f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x16& a_ = WINO ? yac[o][i][j] : acc[i][j];
+                                    *reinterpret_cast<f32x4*>(w + (((o * NT + i) * MT + j) * 4 + g) * 256) =
+                                        f32x4{a_[4 * g], a_[4 * g + 1], a_[4 * g + 2], a_[4 * g + 3]};
+                                }
                     // The two halves of a split tile run on the SAME XCD (workgroups b and b+8), i.e. behind the same L2:
                     // once the stores have been acknowledged (vmcnt 0: the vector L1 is write-through) the partner can
                     // read them -- no L2 write-back / invalidate (an agent-scope release/acquire pair costs ~60 us per
@@ -378,13 +400,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                     __syncthreads();
                     if (tid == 0) __hip_atomic_store(p.wsflags + blockIdx.x, 1 + (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15),
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    it += k1 - k0; first_item = false;
+                    it += u1 - u0; first_item = false;
                     continue;
                 }
-                if (k1 < p.nk) {
+                if (u1 < UN) {
                     // head part: add, in workgroup order, what the following workgroups of this XCD accumulated for the
                     // rest of this tile (one tail part, preceded by middle parts when a range is shorter than a tile)
-                    const long long tile_end = (long long)(it / p.nk + 1) * p.nk;
+                    const long long tile_end = (long long)(it / UN + 1) * UN;
                     for (int k = 1; jb + k < nj; ++k) {
                         const long long s_k = tx * (jb + k) / nj, e_k = tx * (jb + k + 1) / nj;
                         if (s_k >= tile_end) break;
@@ -402,15 +424,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                         __syncthreads();
                         const float* w = p.ws + ((size_t)partner * NW + wid) * PART + lane * 4;
 #pragma unroll
-                        for (int i = 0; i < NT; ++i)
+                        for (int o = 0; o < NO; ++o)
 #pragma unroll
-                            for (int j = 0; j < MT; ++j)
+                            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    const f32x4 t = *reinterpret_cast<const f32x4*>(w + ((i * MT + j) * 4 + g) * 256);
+                                for (int j = 0; j < MT; ++j)
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += t[q];
-                                }
+                                    for (int g = 0; g < 4; ++g) {
+                                        const f32x4 t = *reinterpret_cast<const f32x4*>(w + (((o * NT + i) * MT + j) * 4 + g) * 256);
+                                        f32x16& a_ = WINO ? yac[o][i][j] : acc[i][j];
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) a_[4 * g + q] += t[q];
+                                    }
                     }
                 }
             }
@@ -423,7 +448,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
 #ifdef YV3_TIMELINE
             ++tl_items; tl_chunks += k1 - k0;
 #endif
-            it += k1 - k0; first_item = false;
+            it += u1 - u0; first_item = false;
         }
 #ifdef YV3_TIMELINE
         if (blockIdx.x == 100 && lane == 0 && p.alpha) {     // debug build only: cycle split of one workgroup -> alpha[0..]
@@ -679,7 +704,7 @@ static int launch_wino(const yv3_conv_desc* d, ConvParamsP p, hipStream_t s) {
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
     const long long T = (long long)d->B * th * tw;
     if (T > 0x7fffffffLL || d->cout_pad % 128 || d->cin % 32) return YV3_ESHAPE;
-    if (!d->wino_ws || d->wino_ws_bytes < yv3_wino_workspace_bytes(d->B, d->H, d->W, d->cin)) return YV3_EWORKSPACE;
+    if (!d->wino_ws || d->wino_ws_bytes < (size_t)2 * 16 * T * d->cin * sizeof(u16)) return YV3_EWORKSPACE;
     u16* v = (u16*)d->wino_ws;
     int rc = yv3_wino_input_transform(p.x, p.xs, v, d->B, d->H, d->W, d->cin, s);
     if (rc) return rc;
@@ -689,13 +714,30 @@ static int launch_wino(const yv3_conv_desc* d, ConvParamsP p, hipStream_t s) {
     p.H = 1; p.W = (int)T; p.Ho = 1; p.Wo = (int)T; p.M = (int)T; p.stride = 1;
     p.K = 16 * d->cin; p.nk = p.K / PBK;
     p.tb = 128; p.ntiles = d->cout_pad / 128;
-    p.ws = nullptr; p.wsflags = nullptr; p.ws_bytes = 0;
     constexpr int BM = 128, BN = 128, NS = 4;
     const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
     p.total = (int)grid.x;
     const size_t pipe = (size_t)NS * 2 * (BM + BN) * ROWB, epi = (size_t)8 * 32 * (BN / 2 + 4) * 4;
-    hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, false, 1, 0, true>), grid, dim3(512),
-                       pipe > epi ? pipe : epi, s, p);
+    const size_t lds = pipe > epi ? pipe : epi;
+    // Schedules.  Default: one 128x128 tile (all 16 positions, 16 x Cin/32 chunks) per workgroup -- bitwise independent of the
+    // batch composition.  YV3_OPT_WINO_EVEN: stream-K over transform positions -- one persistent workgroup per CU takes an equal,
+    // contiguous range of (tile, position) units of its XCD and hands partial outputs over inside the XCD's L2 (see the
+    // kernel); a split tile is summed head + tail.  Measured (tools/wino_ab.py, profiles/r03_wino_ab2.log): it only wins below
+    // half a round of tiles (512->1024 @19x19 bs=16: 0.176 vs 0.202 ms) and loses 3...30 % above (256 KB of partial outputs per
+    // split, no dynamic tile dispatch, and a partly filled round simply clocks higher on this power-limited chip): opt-in.
+    const int num_cu = yv3_num_cu();
+    const size_t vbytes = (size_t)2 * 16 * T * d->cin * sizeof(u16);
+    const bool even = (d->options & YV3_OPT_WINO_EVEN) && num_cu <= YV3_WINO_SK_MAX_WG && (long long)p.total * 16 >= num_cu &&
+                      p.total % num_cu != 0 && d->wino_ws_bytes >= vbytes + yv3_wino_sk_bytes();
+    if (even) {
+        p.ws = (float*)((char*)d->wino_ws + ((vbytes + 255) & ~(size_t)255));
+        p.wsflags = (int*)((char*)p.ws + (size_t)YV3_WINO_SK_MAX_WG * YV3_WINO_SK_PART_BYTES);
+        p.ws_bytes = yv3_wino_sk_bytes();
+        hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, true, 1, 0, true>), dim3((unsigned)num_cu), dim3(512), lds, s, p);
+    } else {
+        p.ws = nullptr; p.wsflags = nullptr; p.ws_bytes = 0;
+        hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, false, 1, 0, true>), grid, dim3(512), lds, s, p);
+    }
     YV3_CHECK_LAUNCH();
     return 0;
 }
@@ -749,7 +791,15 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         if (rc != -100) return rc;
     }
     if (d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino &&
-        d->x_plane_stride <= 0 && d->y_plane_stride <= 0) return launch_wino(d, p, s);
+        d->x_plane_stride <= 0 && d->y_plane_stride <= 0) {
+        // Winograd F(2x2,3x3) when its 128x128 tiles (a quarter of the direct kernel's row count) fill 0.55 ... 1.05 rounds of
+        // the chip: same-box A/B against the direct kernel (tools/wino_ab.py): 256->512 @26x26 bs=32 (172 tiles) x1.28,
+        // 512->1024 @13x13 bs=64 (200) x1.36, 256->512 @38x38 bs=16 (184) x1.26; but 340 tiles (1.33 rounds: @26x26 bs=64) x0.96,
+        // 104 tiles (@13x13 bs=32, @19x19 bs=16) x0.78...0.80, and the 128-channel 52x52 layers x0.93 (input transform HBM-bound)
+        const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (npad / 128);
+        const long long ncu = yv3_num_cu();
+        if ((d->options & YV3_OPT_WINO_ALWAYS) || (tiles * 100 >= 55 * ncu && tiles * 100 <= 105 * ncu)) return launch_wino(d, p, s);
+    }
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
                                          np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, use_pp, s) : \

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const u16* __restrict__
 
 extern "C" size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin) {
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0) return 0;
-    return (size_t)2 * 16 * B * ((H + 1) / 2) * ((W + 1) / 2) * cin * sizeof(u16);
+    // transformed input + the hand-over area of the even (stream-K) schedule (parts + flags; must start zero-filled)
+    return (((size_t)2 * 16 * B * ((H + 1) / 2) * ((W + 1) / 2) * cin * sizeof(u16) + 255) & ~(size_t)255) + yv3_wino_sk_bytes();
 }
 
 // V = B^T d B of the [2][B,H,W,C] fp16-plane tensor x (plane stride xs elements) -> v = [2][16][T][C]

@@ -154,6 +154,10 @@ def tuning_options():
         opts |= _ffi.OPT_NO_PINGPONG
     if os.environ.get("YV3_K3S1"):
         opts |= _ffi.OPT_K3S1
+    if os.environ.get("YV3_WINO_EVEN"):
+        opts |= _ffi.OPT_WINO_EVEN
+    if os.environ.get("YV3_WINO_ALWAYS"):
+        opts |= _ffi.OPT_WINO_ALWAYS
     opts |= (int(os.environ.get("YV3_TILE", "0") or 0) & 0xff) << 8
     return opts, int(os.environ.get("YV3_BIG_MIN", "0") or 0)
 
@@ -261,7 +265,7 @@ class Plan:
             wsb = _ffi.lib().yv3_wino_workspace_bytes
             # eligible layers (cin >= 256) read 256 channels at H/16 or 512 at H/32
             need = max(wsb(B, H // 16, W // 16, 256), wsb(B, H // 32, W // 32, 512))
-            self.wino_ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            self.wino_ws = torch.zeros(need, device=dev, dtype=torch.uint8)       # (zero-filled: hand-over flags of the even schedule)
 
         def buf(h, w, c, dtype=dt):
             t = alloc_act(B, h, w, c, dtype, dev)
@@ -402,7 +406,8 @@ class Engine:
         # opt-in (measured null end to end, see batch_split): 13x13 layers as "one full round" + "the rest"
         self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_BATCH_SPLIT") == "1"))
         # Winograd F(2x2,3x3) for the 3x3 stride-1 layers with >= 256 input channels (fp16-plane mode; csrc/winograd.hip)
-        self.winograd = bool(getattr(net, "winograd", os.environ.get("YV3_WINO", "0") == "1"))
+        # (default on: the library uses it per launch when the tile count suits it, yv3_conv_desc.w_wino; YV3_WINO=0 / net.winograd = False: never)
+        self.winograd = bool(getattr(net, "winograd", os.environ.get("YV3_WINO", "1") != "0"))
 
     # -- weights
     def _param_tensors(self):
