@@ -7,7 +7,20 @@ path, B, size = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 NAMES = ("conv_igemm", "conv0_", "conv_planes", "conv_front", "conv_res64")
-convs = [r for r in rows if any(n in r["Kernel_Name"] for n in NAMES)]
+convs = []
+pending = None                      # a Winograd layer = wino_input_kernel + the WINO conv_planes launch: one entry, durations added
+for r in rows:
+    kn = r["Kernel_Name"]
+    if "wino_input_kernel" in kn:
+        pending = r
+        continue
+    if any(n in kn for n in NAMES):
+        if pending is not None:
+            r = dict(r)
+            r["End_Timestamp"] = str(int(r["End_Timestamp"]) + int(pending["End_Timestamp"]) - int(pending["Start_Timestamp"]))
+            r["Kernel_Name"] = kn.replace("conv_planes_kernel<", "winograd+conv_planes_kernel<")
+            pending = None
+        convs.append(r)
 fused_front = any("conv_front" in r["Kernel_Name"] for r in convs)      # feature.mlist.0 + .1 in one launch
 fused_res = any("conv_res64" in r["Kernel_Name"] for r in convs)        # feature.mlist.2 (1x1 + 3x3 + add) in one launch
 specs = arch.conv_specs(); hw = arch.conv_output_hw(size)

@@ -261,7 +261,7 @@ class Plan:
         # Winograd scratch (the transformed input of ONE layer at a time; launches of a plan are stream-ordered): sized for
         # the largest eligible layer of this plan
         self.wino_ws = None
-        if engine.winograd and dt == F32H2:
+        if engine.winograd and dt == F32H2 and not engine.batch_split:      # (batch_split slices the same layers: direct kernels only)
             wsb = _ffi.lib().yv3_wino_workspace_bytes
             # eligible layers (cin >= 256) read 256 channels at H/16 or 512 at H/32
             need = max(wsb(B, H // 16, W // 16, 256), wsb(B, H // 32, W // 32, 512))
