@@ -582,3 +582,34 @@ def test_winograd_conv_vs_fp64(cin, cout, B, H, W, res):
     print("winograd %s: err vs fp64 %.3g tile schedule, %.3g even schedule (direct kernel %.3g)" % ((cin, cout, B, H, W), e, e_t, e_d))
     assert_close_rel(out, direct, 2e-5, "winograd vs direct")
     assert_close_rel(out, ev, 1e-5, "even vs tile schedule")
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W,res", [(64, 128, 2, 20, 28, True), (128, 256, 2, 13, 13, True), (256, 512, 3, 26, 26, False),
+                                                (512, 1024, 2, 13, 13, True), (256, 128, 1, 7, 5, True)])
+def test_winograd_f32_conv_vs_fp64(cin, cout, B, H, W, res):
+    """fp32-MFMA mode (YV3_F32): the Winograd F(2x2,3x3) form of conv_bn_relu(3x3, s1) (+ residual) -- fp32 transforms, fp32
+    MFMA, fp32 fold -- against fp64 (2e-5 * max(1,|ref|), the direct kernel's bar) and against the direct fp32 kernel."""
+    mode = _ffi.F32
+    m = _rand_cbr(cin, cout, 3, 1, seed=cin + cout + H)
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.rand(B, cin, H, W, generator=g) * 2 - 0.5
+    r = (torch.rand(B, cout, H, W, generator=g) - 0.5) if res else None
+    ref = _ref_cbr(m, x) + (r.double() if res else 0)
+    mc = m.cuda()
+    sp = mc._spec()
+    pc = engine.pack_conv(mc, sp, mode, winograd=True)
+    assert pc.w_wino is not None
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    rg = r.cuda().permute(0, 2, 3, 1).contiguous() if res else None
+    y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    ws = torch.zeros(_ffi.lib().yv3_wino_workspace_bytes(B, H, W, cin), dtype=torch.uint8, device="cuda")
+    d = engine.make_desc(pc, xg, y, B, H, W, rg, dtype=mode, wino_ws=ws)
+    d.options |= _ffi.OPT_WINO_ALWAYS
+    assert d.w_wino
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    out = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(out).all(), "an output element was not written"
+    e = assert_close_rel(out, ref, 2e-5, "fp32 winograd conv %s" % ((cin, cout, H, W),))
+    direct = _run_mode(mc, x, mode, r)
+    print("fp32 winograd %s: err vs fp64 %.3g (direct kernel %.3g)" % ((cin, cout, B, H, W), e, float(rel_err(direct, ref).max())))
+    assert_close_rel(out, direct, 2e-5, "fp32 winograd vs direct")

@@ -28,7 +28,11 @@ def main():
     fam = collections.OrderedDict()
     for di, c in disp.items():
         n = c["name"]
-        key = ("conv_planes_kernel<2,256,128> (3x3 / 1x1, 8-wave ping-pong)" if "conv_planes_kernel<2, 256, 128" in n else
+        key = ("wino_input_kernel (Winograd input transform)" if "wino_input" in n else
+               "conv_planes_kernel<2,128,128,...,WINO> (Winograd GEMM stage)" if ("conv_planes_kernel<2, 128, 128" in n and n.rstrip().rstrip(")").rstrip().endswith("true>")) else
+               "conv_planes_kernel<1,256,128,2,2> (bf16, four waves, 128x64 wave tiles)" if "conv_planes_kernel<1, 256, 128, 2, 2" in n else
+               "conv_planes_kernel<1,256,128,4,2> (bf16, 8-wave ping-pong)" if "conv_planes_kernel<1, 256, 128, 4, 2" in n else
+               "conv_planes_kernel<2,256,128> (3x3 / 1x1, 8-wave ping-pong)" if "conv_planes_kernel<2, 256, 128" in n else
                "conv_planes_kernel<2,*> other tiles" if "conv_planes_kernel<2" in n else
                "conv_planes_kernel (other modes)" if "conv_planes" in n else
                "conv_front" if "front" in n else "conv_res64" if "conv_res64" in n else "conv_1x1" if "conv1x1" in n else

@@ -39,6 +39,9 @@ struct ConvParams {
     int cchunks;       // Cin / 32
     int nk;            // K / 32
     int ntiles;        // N tiles
+    // Winograd launches (WINO): rows are 2x2 output tiles, position xi's operand matrix starts xi * xi_stride floats into x
+    long long xi_stride;
+    int wH, wW, wth, wtw;
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_f32[4];      // zero-initialised; NOT const: a constant-address-space pointer would turn the loads into flat_load
@@ -51,9 +54,27 @@ constexpr int LDS_LD = 36;     // floats per LDS row: 32 + 4 pad -> 144-byte pit
 // residual reads are issued as one batch (the straight-from-accumulator epilogue below issues them one dependent dword at a
 // time: ~30 us per 256 x 128 tile).  Same operation order: same bits.
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-template <int MT, int NT>
-__device__ inline void epilogue_lds(const f32x16 (&acc)[MT][NT], const ConvParams& p, float* tile, int mw, int nw, int lane) {
+// WINO: row m = 2x2 output tile m, `acc` = its output (wi, wj) -> pixel (2 ty + wi, 2 tx + wj) (skipped beyond an odd picture's edge)
+template <int MT, int NT, bool WINO = false>
+__device__ inline void epilogue_lds(const f32x16 (&acc)[MT][NT], const ConvParams& p, float* tile, int mw, int nw, int lane, int wi = 0, int wj = 0) {
     constexpr int WTM = MT * 32, WTN = NT * 32, EP = WTN + 4;
+    auto rowpix = [&](int m) -> long long {
+        if constexpr (!WINO) return m < p.M ? (long long)m : -1;
+        else {
+            if (m >= p.M) return -1;
+            const int tt = p.wth * p.wtw;
+            const int b = m / tt;
+            const int rem = m - b * tt;
+            const int ty = rem / p.wtw, tx = rem - ty * p.wtw;
+            const int oy = 2 * ty + wi, ox = 2 * tx + wj;
+            return (oy < p.wH && ox < p.wW) ? ((long long)b * p.wH + oy) * p.wW + ox : -1;
+        }
+    };
+    if constexpr (WINO) {                             // the previous output's rows of this wave's LDS tile have been read
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     constexpr int LPR = WTN / 4, RPP = 64 / LPR, NPASS = WTM / RPP;     // lanes per row, rows per pass, passes
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
@@ -78,22 +99,26 @@ __device__ inline void epilogue_lds(const f32x16 (&acc)[MT][NT], const ConvParam
     if (p.res) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int m = mw + ps * RPP + er;
-            rres[ps] = *reinterpret_cast<const f32x4*>(p.res + (long long)(m < p.M ? m : p.M - 1) * p.Cout + nw + ec);
+            const long long px = rowpix(mw + ps * RPP + er);
+            rres[ps] = *reinterpret_cast<const f32x4*>(p.res + (px >= 0 ? px : 0) * p.Cout + nw + ec);
         }
     }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int r = ps * RPP + er;
-        const int m = mw + r;
+        const long long px = rowpix(mw + r);
         f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * EP + ec);
         if (p.res) { v[0] += rres[ps][0]; v[1] += rres[ps][1]; v[2] += rres[ps][2]; v[3] += rres[ps][3]; }
-        if (m < p.M) *reinterpret_cast<f32x4*>(p.y + (long long)m * p.Cout + nw + ec) = v;
+        if (px >= 0) *reinterpret_cast<f32x4*>(p.y + px * p.Cout + nw + ec) = v;
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool K3, bool DUAL>
+// WINO: Winograd F(2x2,3x3) GEMM stage (csrc/winograd.hip): the K loop walks the 16 transform positions (Cin/32 chunks each,
+// operand matrix xi * xi_stride into V); at the end of a position the product accumulators are folded into the tile's four
+// outputs with the coefficients of A^T x A^T (0 / +-1: exact) and cleared.
+template <int BM, int BN, int WM, int WN, bool K3, bool DUAL, bool WINO = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const ConvParams p) {
+    static_assert(!WINO || (!K3 && !DUAL), "Winograd stage reads a plain tiles x channels matrix per position");
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;      // 32x32 MFMA tiles per wave
     constexpr int SR = 8 * WM * WN;                  // rows staged per pass: 8 threads (float4 each) per 32-float row
@@ -173,6 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const Conv
                 else { src = p.x2; off = aoff2[r] + (c0 - p.Cup); }
             } else {
                 off = aoff[r] + c0;
+                if (WINO) off += (long long)kw * p.xi_stride;          // (kw counts transform positions)
             }
             ra[S][r] = *reinterpret_cast<const f32x4*>(ok ? src + off : g_zero_f32);
         }
@@ -181,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const Conv
             rb[S][r] = *reinterpret_cast<const f32x4*>(p.w + boff[r] + (long long)kc * BK);
         // advance the walking position
         c0 += BK;
-        if (c0 == p.Cin) { c0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
+        if (c0 == p.Cin) { c0 = 0; if (WINO) ++kw; else if (++kw == 3) { kw = 0; ++kh; } }
     };
     auto store_chunk = [&](auto set_, int buf) {
         constexpr int S = decltype(set_)::value;
@@ -202,6 +228,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const Conv
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x16 yac[WINO ? 4 : 1][MT][NT];          // WINO: the tile's four outputs Y[wi][wj] (index 2*wi + wj)
+    if constexpr (WINO) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) yac[o][i][j][e] = 0.f;
+    }
+    int wleft = p.cchunks, wxi = 0;
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -239,6 +277,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const Conv
             // (past the end: zeros into a buffer nobody reads)
             if (kk == 1) store_chunk(std::integral_constant<int, 1 - P>{}, 1 - P);
         }
+        if constexpr (WINO) {
+            if (--wleft == 0) {                                    // end of a transform position: Y += (A^T x A^T)[.][xi] * M
+                wleft = p.cchunks;
+                const int xr = wxi >> 2, xc = wxi & 3;
+                ++wxi;
+                const float r0 = xr < 3 ? 1.f : 0.f, r1 = xr == 0 ? 0.f : (xr == 1 ? 1.f : -1.f);
+                const float q0 = xc < 3 ? 1.f : 0.f, q1 = xc == 0 ? 0.f : (xc == 1 ? 1.f : -1.f);
+                const float sc[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float mv = acc[i][j][e];
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) yac[o][i][j][e] = fmaf(mv, sc[o], yac[o][i][j][e]);
+                            acc[i][j][e] = 0.f;
+                        }
+            }
+        }
         __syncthreads();
     };
     int kc = 0;
@@ -249,6 +308,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const Conv
     if (kc < p.nk) iteration(S0{}, kc);
 
     // ---- epilogue
+    if constexpr (WINO) {                                            // (host: cout % 128 == 0)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            epilogue_lds<MT, NT, true>(yac[o], p, smem + wid * (WTM * (WTN + 4)), m0 + wm * WTM, n0 + wn * WTN, lane, o >> 1, o & 1);
+        return;
+    }
     if ((p.Cout & 3) == 0 && n0 + wn * WTN + WTN <= p.Cout) {       // wave-uniform; the loop's last __syncthreads freed the LDS
         epilogue_lds<MT, NT>(acc, p, smem + wid * (WTM * (WTN + 4)), m0 + wm * WTM, n0 + wn * WTN, lane);
         return;
@@ -294,6 +359,33 @@ int launch(const ConvParams& p, bool k3, bool dual, hipStream_t s) {
 
 }  // namespace
 
+int yv3_wino_input_transform_f32(const float* x, float* v, int B, int H, int W, int C, hipStream_t s);
+
+// Winograd F(2x2,3x3) form of a 3x3 / stride-1 fp32 layer: fp32 MFMA throughout, 2.25x fewer matrix instructions; differs from
+// the direct kernel (an fmaf chain in K order) by fp32 round-off of the re-associated sums.
+static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) {
+    const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
+    const long long T = (long long)d->B * th * tw;
+    if (T > 0x7fffffffLL || d->cout % 128 || d->cout_pad != d->cout || d->cin % 32) return YV3_ESHAPE;
+    if (!d->wino_ws || d->wino_ws_bytes < (size_t)16 * T * d->cin * sizeof(float)) return YV3_EWORKSPACE;
+    float* v = (float*)d->wino_ws;
+    const int rc = yv3_wino_input_transform_f32(p.x, v, d->B, d->H, d->W, d->cin, s);
+    if (rc) return rc;
+    p.x = v; p.xi_stride = T * d->cin;
+    p.w = (const float*)d->w_wino; p.alpha = d->alpha_wino;
+    p.wH = d->H; p.wW = d->W; p.wth = th; p.wtw = tw;
+    p.H = 1; p.W = (int)T; p.Ho = 1; p.Wo = (int)T; p.M = (int)T; p.stride = 1;
+    p.K = 16 * d->cin; p.nk = p.K / BK;
+    p.ntiles = d->cout / 128;
+    constexpr int BM = 128, BN = 128, WM = 4, WN = 2;
+    const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
+    const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+    YV3_CHECK_LAUNCH();
+    return 0;
+}
+
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     ConvParams p;
     p.x = (const float*)d->x; p.x2 = (const float*)d->x2; p.w = (const float*)d->w;
@@ -310,6 +402,12 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     p.cchunks = d->cin / BK;
     p.nk = p.K / BK;
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
+    if (d->w_wino && d->alpha_wino && k3 && d->stride == 1 && !dual && d->cout % 128 == 0 && d->cout_pad == d->cout) {
+        // fp32 MFMA runs at the vector rate, so this layer is matrix-bound whatever its shape: Winograd whenever the 128x128 tiles
+        // (a quarter of the direct kernel's rows) still fill a good part of the chip, or YV3_OPT_WINO_ALWAYS
+        const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (d->cout / 128);
+        if ((d->options & YV3_OPT_WINO_ALWAYS) || tiles * 100 >= 40 * yv3_num_cu()) return launch_wino_f32(d, p, s);
+    }
 
     // Tile selection: widest N tile the layer fills; for launches that would leave most of the
     // 256 CUs idle (small batch at 13x13 / 26x26) fall back to 64x64 tiles for 4x the blocks.

@@ -40,7 +40,7 @@ __global__ void fold_bn_kernel(const float* gamma, const float* bias, const floa
 extern "C" int yv3_pack_conv_weight(const float* w_oihw, void* w_packed, int cout, int cin, int k,
                                     int cout_pad, int dtype, void* stream) {
     if (!w_oihw || !w_packed || cout <= 0 || cin <= 0 || cout_pad < cout) return YV3_EINVAL;
-    if (k != 1 && k != 3 && !(k == 4 && dtype != YV3_F32)) return YV3_ESHAPE;
+    if (k != 1 && k != 3 && k != 4) return YV3_ESHAPE;
     const long long total = (long long)cout_pad * k * k * cin;
     const int blocks = yv3_ceil_div(total, 256);
     hipStream_t s = (hipStream_t)stream;

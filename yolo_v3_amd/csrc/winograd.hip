@@ -77,6 +77,41 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const u16* __restrict__
     }
 }
 
+// fp32 mode (YV3_F32): x NHWC fp32 -> V [16][T][C] fp32, no scaling (fp32 has the range); one thread = one tile x 4 channels
+__global__ __launch_bounds__(256) void wino_input_f32_kernel(const float* __restrict__ x, float* __restrict__ v,
+                                                             int H, int W, int C, int th, int tw, long long T) {
+    const int cg = C >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * cg) return;
+    const long long t = i / cg;
+    const int c = (int)(i - t * cg) * 4;
+    const int b = (int)(t / (th * tw));
+    const int rem = (int)(t - (long long)b * th * tw);
+    const int ty = rem / tw, tx = rem - ty * tw;
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y0 + r, xx = x0 + q;
+            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            d[r][q] = ok ? *reinterpret_cast<const f32x4*>(x + (((long long)b * H + yy) * W + xx) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 d0 = d[0][q], d1 = d[1][q], d2 = d[2][q], d3 = d[3][q];
+        d[0][q] = d0 - d2; d[1][q] = d1 + d2; d[2][q] = d2 - d1; d[3][q] = d1 - d3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const f32x4 t0 = d[r][0], t1 = d[r][1], t2 = d[r][2], t3 = d[r][3];
+        const f32x4 o[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(v + ((long long)(r * 4 + q) * T + t) * C + c) = o[q];
+    }
+}
+
 }  // namespace
 
 extern "C" size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin) {
@@ -92,6 +127,17 @@ int yv3_wino_input_transform(const u16* x, long long xs, u16* v, int B, int H, i
     const long long T = (long long)B * th * tw;
     const long long n = T * (C >> 3);
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, xs, v, 16 * T * C, H, W, C, th, tw, T);
+    YV3_CHECK_LAUNCH();
+    return 0;
+}
+
+// fp32 form: x NHWC fp32 [B,H,W,C] -> v = [16][T][C] fp32
+int yv3_wino_input_transform_f32(const float* x, float* v, int B, int H, int W, int C, hipStream_t s) {
+    if ((C & 3) || B <= 0) return YV3_ESHAPE;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long long T = (long long)B * th * tw;
+    const long long n = T * (C >> 2);
+    hipLaunchKernelGGL(wino_input_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v, H, W, C, th, tw, T);
     YV3_CHECK_LAUNCH();
     return 0;
 }

@@ -80,17 +80,33 @@ WINO_MIN_CIN = int(os.environ.get("YV3_WINO_MIN_CIN", "256") or 256)     # Winog
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
+WINO_MIN_CIN_F32 = 64  # exact-fp32 mode: fp32 MFMA runs at the vector rate, every 3x3 layer is matrix-bound -> from the 104x104 layers down
+
+
 def wino_eligible(spec, dtype):
-    return dtype == F32H2 and spec.k == 3 and spec.stride == 1 and spec.cin >= WINO_MIN_CIN and spec.bn
+    if not (spec.k == 3 and spec.stride == 1 and spec.bn):
+        return False
+    if dtype == F32H2:
+        return spec.cin >= WINO_MIN_CIN
+    return dtype == F32 and spec.cin >= WINO_MIN_CIN_F32 and spec.cout % 128 == 0
 
 
-def pack_wino(weight_f32, alpha_bn, spec, cout_pad):
-    """U = G g G^T (fp64 -> fp32) of every 3x3 filter, per-output-channel power-of-two scaling as for the direct weights,
-    packed as a 16-tap ("k = 4") filter bank; alpha_wino = alpha * 2^-e * 4 (the input transform carries a factor 1/4)."""
+def pack_wino(weight_f32, alpha_bn, spec, cout_pad, dtype=F32H2):
+    """U = G g G^T (fp64 -> fp32) of every 3x3 filter, packed as a 16-tap ("k = 4") filter bank.  F32H2: per-output-channel
+    power-of-two scaling as for the direct weights, alpha_wino = alpha * 2^-e * 4 (the input transform carries a factor
+    1/4).  F32: plain fp32 U, alpha_wino = alpha."""
     lib = _ffi.lib()
     dev = weight_f32.device
-    G = torch.tensor(_WINO_G, dtype=torch.float64, device=dev)
-    U = torch.einsum("ij,ocjk,lk->ocil", G, weight_f32.double(), G).float().contiguous()            # [cout, cin, 4, 4]
+    # U[o,c,i,l] = sum_jk G[i,j] g[o,c,j,k] G[l,k] in fp64, as 24 scaled adds (elementwise torch ops: no vendor GEMM anywhere)
+    g64 = weight_f32.double()
+    t = torch.stack([sum(_WINO_G[i][j] * g64[:, :, j, :] for j in range(3) if _WINO_G[i][j] != 0.0) for i in range(4)], 2)      # [O,C,4,3]
+    U = torch.stack([sum(_WINO_G[l][k] * t[:, :, :, k] for k in range(3) if _WINO_G[l][k] != 0.0) for l in range(4)], 3)        # [O,C,4,4]
+    U = U.float().contiguous()
+    if dtype == F32:
+        wp = torch.empty(cout_pad * 16 * spec.cin, device=dev, dtype=torch.float32)
+        _ffi.check(lib.yv3_pack_conv_weight(U.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, 4, cout_pad, F32, _ffi.stream_ptr()),
+                   "yv3_pack_conv_weight(k=4)")
+        return wp, alpha_bn.clone()
     umax = U.abs().amax(dim=(1, 2, 3))
     e = torch.where(umax > 0, -torch.floor(torch.log2(umax.clamp(min=1e-38))), torch.zeros_like(umax)).clamp(-100.0, 100.0)
     U = (U * torch.exp2(e).view(-1, 1, 1, 1)).contiguous()
@@ -141,7 +157,7 @@ def pack_conv(module, spec, dtype, winograd=False):
     _ffi.check(lib.yv3_pack_conv_weight(w32.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, spec.k,
                                         cout_pad, dtype, s), "yv3_pack_conv_weight")
     if winograd and wino_eligible(spec, dtype):
-        ww, aw = pack_wino(w_orig, alpha_bn, spec, cout_pad)
+        ww, aw = pack_wino(w_orig, alpha_bn, spec, cout_pad, dtype)
         return PackedConv(spec, wp, alpha, beta, cout_pad, ww, aw)
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
@@ -205,7 +221,7 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
     d.flags = _ptr(flags)
     d.workspace = _ptr(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
-    if wino_ws is not None and pc.w_wino is not None and batch is None and dtype == F32H2 and (out_dtype is None or out_dtype == dtype):
+    if wino_ws is not None and pc.w_wino is not None and batch is None and dtype in (F32H2, F32) and (out_dtype is None or out_dtype == dtype):
         d.w_wino, d.alpha_wino = _ptr(pc.w_wino), _ptr(pc.alpha_wino)
         d.wino_ws, d.wino_ws_bytes = _ptr(wino_ws), wino_ws.numel() * wino_ws.element_size()
     if batch is not None:
@@ -261,10 +277,10 @@ class Plan:
         # Winograd scratch (the transformed input of ONE layer at a time; launches of a plan are stream-ordered): sized for
         # the largest eligible layer of this plan
         self.wino_ws = None
-        if engine.winograd and dt == F32H2 and not engine.batch_split:      # (batch_split slices the same layers: direct kernels only)
+        if engine.winograd and dt in (F32H2, F32) and not engine.batch_split:      # (batch_split slices the same layers: direct kernels only)
             wsb = _ffi.lib().yv3_wino_workspace_bytes
-            # eligible layers (cin >= 256) read 256 channels at H/16 or 512 at H/32
-            need = max(wsb(B, H // 16, W // 16, 256), wsb(B, H // 32, W // 32, 512))
+            # eligible layers read 64 channels at H/4 (F32 only), 128 at H/8, 256 at H/16, 512 at H/32: the shallowest one is the largest
+            need = wsb(B, H // 4, W // 4, 64) if dt == F32 else max(wsb(B, H // 16, W // 16, WINO_MIN_CIN), wsb(B, H // 32, W // 32, 512))
             self.wino_ws = torch.zeros(need, device=dev, dtype=torch.uint8)       # (zero-filled: hand-over flags of the even schedule)
 
         def buf(h, w, c, dtype=dt):
