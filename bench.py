@@ -160,7 +160,7 @@ class Workload:
     """One (weights, batch, size, mode, thresholds) configuration measured through the product entry:
     `Detector.run_device` (world 1) / `ShardedDetector.run_device` (world > 1: + the one all-gather)."""
 
-    def __init__(self, net, x, mode, conf, nms, is_eval=False, world=1, cap_host=512, max_cand=None, lanes=None, pipeline=False):
+    def __init__(self, net, x, mode, conf, nms, is_eval=False, world=1, cap_host=512, max_cand=None, lanes=None):
         from yolo_v3_amd import Detector, _ffi
         from yolo_v3_amd import dist as ydist
         codes = {"f32": _ffi.F32, "bf16": _ffi.BF16, "f32x3": _ffi.F32X3, "f32h2": _ffi.F32H2}
@@ -180,10 +180,6 @@ class Workload:
         self.host_counts = torch.empty((2 * B,), dtype=torch.int32).pin_memory()
         self.events = []
         self.gathered = None
-        # pipeline: Detector.run_pipelined -- the next step's convolutions overlap this step's filter + NMS (two result slots);
-        # the D2H copy of a step's results runs on a copy stream behind that step's events
-        self.pipeline = bool(pipeline) and self.sd is None
-        self.copy_stream = torch.cuda.Stream(device=x.device) if self.pipeline else None
 
     def step(self, timed):
         marks = {}
@@ -193,14 +189,6 @@ class Workload:
             ev.record()                                   # on torch's current stream == the kernels' launch stream
             marks[name] = ev
 
-        if self.pipeline:
-            boxes, counts, evs = self.det.run_pipelined(self.x)
-            with torch.cuda.stream(self.copy_stream):
-                for e in evs:
-                    self.copy_stream.wait_event(e)
-                self.host.copy_(boxes[:, :self.cap_host], non_blocking=True)
-                self.host_counts.copy_(counts, non_blocking=True)
-            return
         if self.sd is not None:
             self.gathered = self.sd.run_device(self.x, mark if timed else None)      # product code: conv0 ... NMS, pack, all-gather
             self.host.copy_(self.gathered, non_blocking=True)
@@ -271,15 +259,6 @@ class Workload:
         return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, plan.n_desc - plan.first_desc
 
     def summary(self, elapsed, steps):
-        if self.pipeline:
-            fa, _, _ = self.flops()
-            ms = elapsed / steps * 1e3
-            return {"dtype": DTYPE_NAME[self.mode], "value": round(self.B * steps / elapsed, 2), "unit": "images/sec",
-                    "ms_per_step": round(ms, 4), "ms_per_img": round(ms / self.B, 5), "lanes": self.det.lanes,
-                    "entry": "Detector.run_pipelined (step i+1's convolutions overlap step i's filter + NMS; D2H on a copy stream)",
-                    "roofline": {"bound": "mfma", "kernel": "all 75 convs' FLOPs over the whole step time", "peak": round(PEAK_TFLOPS[self.mode], 2),
-                                 "unit": "TFLOP/s", "achieved": round(fa / (ms * 1e-3) / 1e12, 2),
-                                 "frac": round(fa / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[self.mode], 4), "launches": 75}}
         st = self.stages_ms()
         fa, fi, nl = self.flops()
         ach = fi / (st["convs"] * 1e-3) / 1e12
@@ -511,6 +490,7 @@ def main():
             w = Workload(net, x, mode, args.conf, args.nms)
             out["modes"][mode] = w.summary(w.run(sub_steps, sub_warm), sub_steps)
             w.finish()
+            attach_traffic(out["modes"][mode]["roofline"], mode, args.size, B, out["modes"][mode]["roofline"]["launches"])
             if mode == "bf16":
                 out["modes"][mode]["note"] = "reduced precision (bf16 conv operands, fp32 accumulate / epilogue / decode): outside the 1e-4 parity bar"
             del w
@@ -532,8 +512,6 @@ def main():
         dnet = make_net(synth.dense_weight_stream(), 608, dev)
         sub("4", "608x608 bs=8 SW-dense (>=5k pre-NMS rows/img) f32h2 conf=0.5 nms=0.4", dnet, scenes(8, 608, 4, dev), "f32h2", 0.5, 0.4,
             cap_host=8192)
-        sub("4_pipelined", "the same workload through Detector.run_pipelined (throughput mode)", dnet, scenes(8, 608, 4, dev), "f32h2", 0.5, 0.4,
-            cap_host=8192, pipeline=True)
         del dnet
         enet = make_net(synth.eval_weight_stream(), 416, dev)
         xe = scenes(32, 416, 5, dev)

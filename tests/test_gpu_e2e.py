@@ -399,6 +399,7 @@ def test_batch_split_schedule_is_bit_identical(sw1_stream):
     as two launches over batch slices, 48 + 16 images (yv3_conv_desc.*_plane_stride): same kernels, same K order ->
     detections bit-identical to the one-launch plan; the plan really contains the extra launches."""
     net = load_sw1_net(sw1_stream).cuda()
+    net.winograd = False                                     # (a batch-split plan keeps the direct kernels: compare like with like)
     x = torch.from_numpy(synth.images(64, 416, 4243)).cuda()
     eng = net.engine()
     outs = []
@@ -494,35 +495,3 @@ def test_eval_detect_fused_equals_two_phase(sw1_stream):
     assert len(net._detectors) <= dmod.DETECTOR_CACHE_MAX
     detect(net, x, 80, 0.5, 0.4)
     assert sum(1 for k, v in net._detectors.items() if ids.get(k) in (None, id(v))) == len(net._detectors)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_pipelined_detector_equals_run_device(sw1_stream, lanes):
-    """Detector.run_pipelined (throughput mode: the next call's convolutions overlap this call's filter + NMS; two result
-    slots, post-processing on its own stream per lane) returns bit for bit what run_device returns, call after call, for
-    alternating inputs (slot reuse: call i+2 must wait for the post-processing that read the slot)."""
-    net = load_sw1_net(synth.dense_weight_stream(), 416).cuda()
-    B = 6
-    xs = [torch.from_numpy(synth.images(B, 416, 300 + i)).cuda() for i in range(3)]
-    det = Detector(net, B, 416, 416, lanes=lanes, cap=4096)
-    want = []
-    for x in xs:
-        b, c = det.run_device(x)
-        torch.cuda.synchronize()
-        want.append((b.clone(), c.clone()))
-    got = []
-    for i in range(7):                                           # back to back, no host sync in between
-        b, c, ev = det.run_pipelined(xs[i % 3])
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            for e in ev:
-                side.wait_event(e)
-            got.append((b.clone(), c.clone(), i % 3))
-    torch.cuda.synchronize()
-    assert int(want[0][1][B:].max()) > 100
-    for b, c, k in got:
-        assert torch.equal(c, want[k][1])
-        for img in range(B):
-            n = int(c[B + img])
-            assert torch.equal(b[img, :n], want[k][0][img, :n])

@@ -29,7 +29,7 @@ def main():
     for di, c in disp.items():
         n = c["name"]
         key = ("wino_input_kernel (Winograd input transform)" if "wino_input" in n else
-               "conv_planes_kernel<2,128,128,...,WINO> (Winograd GEMM stage)" if ("conv_planes_kernel<2, 128, 128" in n and n.rstrip().rstrip(")").rstrip().endswith("true>")) else
+               "conv_planes_kernel<2,128,128,...,WINO> (Winograd GEMM stage)" if ("conv_planes_kernel<2, 128, 128" in n and ", true>(" in n) else
                "conv_planes_kernel<1,256,128,2,2> (bf16, four waves, 128x64 wave tiles)" if "conv_planes_kernel<1, 256, 128, 2, 2" in n else
                "conv_planes_kernel<1,256,128,4,2> (bf16, 8-wave ping-pong)" if "conv_planes_kernel<1, 256, 128, 4, 2" in n else
                "conv_planes_kernel<2,256,128> (3x3 / 1x1, 8-wave ping-pong)" if "conv_planes_kernel<2, 256, 128" in n else

@@ -225,79 +225,6 @@ class Detector:
                 self._enqueue(x, mark)
         return self.boxes, self.counts
 
-    # -- pipelined (throughput) mode: call i+1's convolutions overlap call i's post-processing
-    def _build_pipeline(self):
-        """Two result slots (detections, boxes, counts) and one post-processing stream per lane.  Lane l's conv stream runs
-        front -> convs (-> decode) of call i into slot i % 2, its post stream runs filter + NMS behind it; the conv stream goes
-        straight on with call i+1 (other slot), waiting only for the post-processing that last READ that slot (call i-1)."""
-        B = self.shape[0]
-        nc = self.net.numClass
-        self._pl_slots = []
-        for _ in range(2):
-            dets = torch.empty_like(self.dets)
-            boxes = torch.empty_like(self.boxes)
-            counts = torch.zeros_like(self.counts)
-            pps = [PostProcessor(p.B, self.N, nc, self.device, max_cand=self.max_cand, cap=self.cap,
-                                 counts=(counts[off:off + p.B], counts[B + off:B + off + p.B]), out=boxes[off:off + p.B])
-                   for p, off in zip(self.lane_plans, self.lane_off)]
-            self._pl_slots.append({"dets": dets, "boxes": boxes, "counts": counts, "pp": pps, "done": [None] * len(pps)})
-        self._pl_conv = self.lane_streams or [torch.cuda.Stream(device=self.device)]
-        self._pl_post = [torch.cuda.Stream(device=self.device) for _ in self.lane_plans]
-        self._pl_calls = 0
-        self._pl_generation = self._generation
-
-    def run_pipelined(self, imgs):
-        """Throughput form of `run_device`: enqueue one batch and return ``(boxes, counts, events)`` WITHOUT making the current
-        stream wait -- the results of this call are complete when all `events` have fired (``for e in events:
-        stream.wait_event(e)`` on whichever stream consumes them; `wait_pipelined` does it for the current stream).  Each lane
-        runs its filter + NMS on a second stream of its own, so the next call's convolutions start while this call's
-        post-processing is still running (two result slots, alternating).  Same kernels, same order per image: results are
-        bit-identical to `run_device`'s.  The caller must leave `imgs` untouched until the events have fired, and must
-        consume a slot's results before the call after next overwrites them."""
-        x = self.engine.prepare_input(imgs)
-        if tuple(x.shape) != self.shape:
-            raise _ffi.Yv3Error("Detector was built for %s, got %s" % (self.shape, tuple(x.shape)))
-        noop = lambda name: None
-        with torch.cuda.device(self.device):
-            self.engine.ensure_packed()
-            if self.engine.generation != self._generation:
-                self._generation = self.engine.generation
-                self._build_plans(self.lanes, self.lane_streams or None)
-                self._graph = None
-            if getattr(self, "_pl_slots", None) is None or self._pl_generation != self._generation:
-                self._build_pipeline()
-            slot = self._pl_slots[self._pl_calls % 2]
-            self._pl_calls += 1
-            main = torch.cuda.current_stream()
-            fork = torch.cuda.Event()
-            fork.record(main)
-            events = []
-            for l, (p, off) in enumerate(zip(self.lane_plans, self.lane_off)):
-                cs, ps = self._pl_conv[l], self._pl_post[l]
-                cs.wait_event(fork)
-                if slot["done"][l] is not None:
-                    cs.wait_event(slot["done"][l])               # the post-processing of two calls ago has read this slot
-                di = slot["dets"][off:off + p.B]
-                with torch.cuda.stream(cs):
-                    self._lane_body(p, None, x[off:off + p.B], di, noop, post=False)
-                    conv_done = torch.cuda.Event()
-                    conv_done.record(cs)
-                ps.wait_event(conv_done)
-                with torch.cuda.stream(ps):
-                    pp = slot["pp"][l]
-                    pp.filter(di, self.conf, self.is_eval, prob=True)
-                    pp.nms(di, self.nms_thr, self.use_nms, self.max_cand, self.cap)
-                    done = torch.cuda.Event()
-                    done.record(ps)
-                slot["done"][l] = done
-                events.append(done)
-        return slot["boxes"], slot["counts"], events
-
-    def wait_pipelined(self, events):
-        s = torch.cuda.current_stream()
-        for e in events:
-            s.wait_event(e)
-
     def to_list(self, boxes, counts_host):
         return boxes_to_list(boxes, counts_host, self.shape[0], self.max_cand)
 
