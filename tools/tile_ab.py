@@ -42,6 +42,8 @@ for name in names:
             _ffi.check(lib.yv3_conv2d(d, st))
     torch.cuda.synchronize()
     same = [bool(torch.equal(outs[0], o)) for o in outs]
+    f0 = engine.from_planes(outs[0], dt).float()
+    dmax = [float((engine.from_planes(o, dt).float() - f0).abs().max()) for o in outs]
     best = [1e9] * len(variants)
     for rep in range(3):                         # interleaved passes
         for i, d in enumerate(descs):
@@ -52,5 +54,5 @@ for name in names:
             e1.record(); torch.cuda.synchronize()
             best[i] = min(best[i], e0.elapsed_time(e1) / iters)
     print("%-5s B=%d %dx%d %d->%d k%d s%d :" % (name, B, H, H, cin, cout, k, s) +
-          "".join("  tile %d: %.4f ms %.0f TF%s" % (v, t, fl / t / 1e9, "" if ok else " (DIFFERS)") for v, t, ok in zip(variants, best, same)))
+          "".join("  tile %d: %.4f ms %.0f TF%s" % (v, t, fl / t / 1e9, "" if ok else " (differs: max|d| %.3g)" % dm) for v, t, ok, dm in zip(variants, best, same, dmax)))
     sys.stdout.flush()
