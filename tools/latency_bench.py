@@ -6,8 +6,9 @@ from yolo_v3_amd import synth, Detector, _ffi
 from tests.helpers import load_sw1_net
 torch.cuda.set_device(0)
 net = load_sw1_net(synth.weight_stream()).cuda()
-net.stream_k = os.environ.get("YV3_SK") == "1"
-modes = {"f32h2": _ffi.F32H2, "f32x3": _ffi.F32X3, "f32": _ffi.F32, "bf16": _ffi.BF16}
+if os.environ.get("YV3_SK") in ("0", "1"):
+    net.stream_k = os.environ["YV3_SK"] == "1"
+modes = {"f32h2": _ffi.F32H2} if os.environ.get("ONLY_DEFAULT") else {"f32h2": _ffi.F32H2, "f32x3": _ffi.F32X3, "f32": _ffi.F32, "bf16": _ffi.BF16}
 for B in [int(b) for b in (sys.argv[1:] or ["1", "4", "16"])]:
     x = torch.from_numpy(synth.images(B, 416, 7)).cuda()
     for name, mode in modes.items():
