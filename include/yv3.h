@@ -284,7 +284,11 @@ int yv3_postproc_nms(const float* dets, int B, int N, int num_class, float nms_t
  * img_hwc uint8 RGB [H,W,3] (device) -> out_chw fp32 [3,out_h,out_w] in [0,1]: cv2.resize(INTER_CUBIC) -- OpenCV's
  * fixed-point 8-bit path: A=-0.75 coefficients as 11-bit shorts, int32 horizontal pass, (sum + 2^21) >> 22 vertical
  * pass, no antialias -- to box = int(size*min(out_w/W,out_h/H)), centred (offset out/2 - box/2, utils.py:34-42) on
- * a 128-grey canvas.  Pass out_chw = batch + b*3*out_h*out_w. */
+ * a 128-grey canvas.  Pass out_chw = batch + b*3*out_h*out_w.
+ * PARITY WITH cv2 IS UNPINNED: cv2 is absent from the build image, so the kernel is checked bit for bit against a
+ * restatement of OpenCV's scalar fixed-point path (oracle_cpu.cv_resize_cubic_u8), not against cv2 output.  SIMD builds
+ * of OpenCV run the vertical cubic pass in float32 (VResizeCubicVec_32s8u) and can differ from the scalar formula by
+ * 1 LSB on ~1e-4 of the pixels: expect agreement with a given cv2 build to within 1 LSB (1/255 of the input), unverified. */
 int yv3_letterbox(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
                   void* stream);
 
