@@ -790,7 +790,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
         if (rc != -100) return rc;
     }
-    if (d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino &&
+    if (d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino && npad % 128 == 0 &&
         d->x_plane_stride <= 0 && d->y_plane_stride <= 0) {
         // Winograd F(2x2,3x3) when its 128x128 tiles (a quarter of the direct kernel's row count) fill 0.55 ... 1.05 rounds of
         // the chip: same-box A/B against the direct kernel (tools/wino_ab.py): 256->512 @26x26 bs=32 (172 tiles) x1.28,
