@@ -12,7 +12,9 @@ final ``[B, cap, 7]`` boxes and their counts.  ``Detector`` keeps the buffers (a
 captured HIP graph of the whole pipeline) alive across calls.
 
 Lanes.  A batch of about 12 or more 416 x 416 images (8 at 608 x 608) runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
-kernels with the same K order, so the detections are bit-identical, but the two launch sequences run concurrently
+kernels with the same K order -- bit-identical detections on the direct kernels (``net.winograd = False``); with the default
+per-launch choice between the direct and the Winograd form of a 3x3 layer (it depends on the sub-batch's tile count) the two
+schedules agree within fp32 round-off -- but the two launch sequences run concurrently
 and fill each other's partially occupied rounds of the chip (at bs=64 the 13x13 layers have 1.34 rounds of tiles,
 the 26x26 layers 2.64, ...) and overlap HBM-bound layers with matrix-bound ones: conv section 13.97 -> 12.65 ms
 (tools/lanes_probe.py).  HIP maps streams onto a few hardware queues and two streams on the SAME queue serialise
@@ -52,8 +54,7 @@ class Detector:
         self._lanes_req = lanes
         with torch.cuda.device(self.device):
             B = batch
-            probe = Plan.geometry(self.engine, height, width)            # (rows N, attributes) without allocating a plan
-            n, attrib = probe
+            n, attrib = Plan.geometry(self.engine, height, width)        # (rows N, attributes) without allocating a plan
             self.N = n
             self.max_cand = int(max_cand or (min(n * net.numClass, 16384) if is_eval else n))
             self.cap = int(cap or self.max_cand)
@@ -113,9 +114,11 @@ class Detector:
 
     def _run_lanes(self, x, mark, post=True):
         """Every lane's pipeline; returns on the current stream with all lanes joined.  With two lanes each lane runs its
-        OWN filter + NMS on its own stream, so one lane's post-processing overlaps the other lane's convolutions (the
-        dense-scene configuration spends 19 % of a step there); the stage marks of a multi-lane step are 'conv0' = fork,
-        'convs' ... 'nms' = join (all of it is the concurrent section)."""
+        OWN filter + NMS on its own stream into its image range of the shared result tensor (no join before the
+        post-processing).  Measured neutral against post-processing the joined batch (the 8-wave conv workgroups
+        fill every CU's register file, so NMS kernels only run in the gaps between conv launches whatever the stream layout);
+        the stage marks of a multi-lane step are 'conv0' = fork, 'convs' ... 'nms' = join (all of it is the concurrent
+        section)."""
         noop = lambda name: None
         if self.lanes == 1:
             self._lane_body(self.plan, self.lane_pp[0], x, self.dets, mark, post)
