@@ -307,6 +307,15 @@ int yv3_resize_linear(const unsigned char* img_hwc, int H, int W, float* out_chw
 int yv3_correct_boxes(const float* boxes, int B, int cap, int ld, const int* counts, const int* org_wh,
                       int img_w, int img_h, int is_letterbox, int out_xyxy, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU.  There is deliberately no yv3_gather_boxes() here (SURVEY.md section 8b lists one in its minimum set): the
+ * path's only collective -- ONE all-gather of the [B_local, cap + 1, 7] fp32 payload, i.e. the [B, cap, 7] output of
+ * yv3_postproc_nms plus one row per image carrying its int32 candidate count, kept count and the status word
+ * (yv3_conv_desc.flags), bit-cast -- is issued by the host side through torch.distributed (backend "nccl" = RCCL over xGMI),
+ * as BASELINE.json's north_star prescribes; a C entry point would only wrap ncclAllGather on a communicator the Python side
+ * owns.  The payload layout is yolo_v3_amd/dist.py:pack_payload / unpack_payload.
+ * ------------------------------------------------------------------------------------------ */
+
 #ifdef __cplusplus
 }
 #endif
