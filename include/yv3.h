@@ -308,7 +308,7 @@ int yv3_correct_boxes(const float* boxes, int B, int cap, int ld, const int* cou
                       int img_w, int img_h, int is_letterbox, int out_xyxy, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Multi-GPU.  There is deliberately no yv3_gather_boxes() here (SURVEY.md section 8b lists one in its minimum set): the
+ * Multi-GPU.  There is deliberately no gather-boxes entry point here (SURVEY.md section 8b lists one in its minimum set): the
  * path's only collective -- ONE all-gather of the [B_local, cap + 1, 7] fp32 payload, i.e. the [B, cap, 7] output of
  * yv3_postproc_nms plus one row per image carrying its int32 candidate count, kept count and the status word
  * (yv3_conv_desc.flags), bit-cast -- is issued by the host side through torch.distributed (backend "nccl" = RCCL over xGMI),
