@@ -841,7 +841,8 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // 64->128 @152 559 -> 691, the stride-2 layers +11...18 %, 256->128 1x1 @76 +12 %; 416x416 bs=64: @52 663 -> 831, @26 825 -> 901,
         // @13 702 -> 846.  Below one tile per CU (512->1024 @19 at bs=16: 184 tiles, 1x1 layers at 38 / 19) the 8-wave ping-pong
         // tile wins by 7...30 % (twice the waves per tile).  A 256x256 / 8-wave tile (code 6) loses to both at these sizes.
-        if (np == 1 && force == 0 && blocks256 >= 256 && !out_f32) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2>(p, k3, dual, out_f32, false, s);
+        // (tune[2] > 0: threshold override for A/B measurements)
+        if (np == 1 && force == 0 && blocks256 >= (p.tune[2] > 0 ? p.tune[2] : 256) && !out_f32) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2>(p, k3, dual, out_f32, false, s);
         if (np == 1 && use_pp && force == 0 && blocks256 >= big_min) return launch_cfg<1, 256, 128, 4, 2, 6>(p, k3, dual, out_f32, true, s);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
         return YV3_CFG(128, 128, 4, 2, 3);
