@@ -74,3 +74,23 @@ def test_sharded_path_issues_one_collective(nccl_world1, sw1_stream):
     res = sd.assemble(gathered, [(0, 4)])
     want = detect(net, x)
     assert all(torch.equal(a, b) for a, b in zip(res, want))
+
+
+def test_bench_two_ranks_on_this_gpu_over_gloo():
+    """bench.py's N > 1 path end to end on the one GPU of this box: `python bench.py --gpus 2` re-launches itself as two ranks
+    (YV3_DIST_BACKEND=gloo: the ranks share the GPU, gloo carries the gather), each runs the product's sharded step
+    (`ShardedDetector.run_device`: pipeline -> pack -> ONE all-gather) and rank 0 prints one JSON line with n_gpus = 2 -- the
+    launch line, rendezvous, shard seeds, collective, max-over-ranks timing and `assemble` of the driver's multi-GPU runs."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["YV3_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "3", "--warmup", "1",
+                        "--lanes", "1", "--no-extras"], cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["entry"].startswith("ShardedDetector.run_device") and "[8, 513, 7]" in out["config"]["collective"]
+    assert out["value"] > 0 and "gather" in out["stages_ms"] and len(out["config"]["boxes_kept_first_images"]) == 4
