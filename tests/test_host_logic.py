@@ -194,3 +194,40 @@ def test_batch_split_rule():
     assert batch_split(64, 13, 13, 96, 256) is None                  # channel count not tiled by 128
     b0, b1 = batch_split(64, 13, 13, 1024, 256)
     assert -(-(b0 * 169) // 256) * 8 <= 256 < -(-((b0 + 1) * 169) // 256) * 8
+
+
+def test_payload_pack_unpack_round_trip():
+    """dist.pack_payload / unpack_payload (the ONE tensor the sharded path all-gathers): boxes bit for bit, int32 counts and
+    status word (any bit pattern, incl. the sign bit and patterns that are NaNs as floats) through the fp32 row."""
+    import torch
+    from yolo_v3_amd import dist as ydist
+    B, cap = 5, 9
+    boxes = torch.randn(B, cap + 3, 7)                            # more rows than travel: only `cap` of them are packed
+    cand = torch.tensor([0, 1, 2 ** 31 - 1, 12345, 7], dtype=torch.int32)
+    kept = torch.tensor([0, 1, 9, 3, 7], dtype=torch.int32)
+    for status in (0, 1, 2, -1, 0x7fc00000, -2 ** 31):
+        payload = torch.empty(B, cap + 1, 7)
+        out = ydist.pack_payload(boxes, cand, kept, torch.tensor([status], dtype=torch.int32), payload)
+        assert out is payload and payload.shape == (B, cap + 1, 7)
+        bx, meta = ydist.unpack_payload(payload.clone())
+        assert torch.equal(bx, boxes[:, :cap])
+        assert meta[:, 0].tolist() == cand.tolist() and meta[:, 1].tolist() == kept.tolist() and meta[:, 2].tolist() == [status] * B
+    # the world-of-one gather is the identity (no process group)
+    assert ydist.gather_payload(payload) is payload
+    res, st = ydist.assemble_global(ydist.pack_payload(boxes, kept, kept, torch.zeros(1, dtype=torch.int32)), [(0, B)], B, max_cand=100)
+    assert st == 0 and [int(r.shape[0]) if r.numel() else 0 for r in res] == kept.tolist()
+
+
+def test_winograd_eligibility_and_geometry():
+    """Which layers carry Winograd-domain filters (engine.wino_eligible) and the plan geometry helper."""
+    from yolo_v3_amd import engine, arch, _ffi
+
+    class E:
+        num_class = 80
+    assert engine.Plan.geometry(E, 416, 416) == (10647, 85) and engine.Plan.geometry(E, 608, 608) == (22743, 85)
+    specs = arch.conv_specs()
+    h2 = [s for s in specs if engine.wino_eligible(s, _ffi.F32H2)]
+    f32 = [s for s in specs if engine.wino_eligible(s, _ffi.F32)]
+    assert len(h2) == 18 and all(s.k == 3 and s.stride == 1 and s.cin >= 256 for s in h2)          # 11 x 256->512, 7 x 512->1024
+    assert len(f32) == 31 and all(s.cout % 128 == 0 and s.cin >= 64 for s in f32)                  # + 11 x 128->256, 2 x 64->128
+    assert not any(engine.wino_eligible(s, _ffi.BF16) or engine.wino_eligible(s, _ffi.F32X3) for s in specs)
