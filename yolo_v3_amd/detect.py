@@ -231,14 +231,14 @@ class Detector:
     def to_list(self, boxes, counts_host):
         return boxes_to_list(boxes, counts_host, self.shape[0], self.max_cand)
 
-    HOST_CAP = 512          # kept boxes per image that travel with the first (and normally only) D2H copy
+    HOST_CAP, HOST_CAP_EVAL = 512, 4096      # kept boxes per image that travel with the first (and normally only) D2H copy
 
     def fetch(self, boxes, counts):
         """The path's single host synchronisation: counts + status word + the first HOST_CAP box rows of every image go to
         pinned host buffers with asynchronous copies behind the kernels, then ONE stream sync.  Returns (host counts [2B],
         host boxes or -- when an image kept more than HOST_CAP boxes -- the device tensor, status word)."""
         B = self.shape[0]
-        hc = min(self.cap, self.HOST_CAP)
+        hc = min(self.cap, self.HOST_CAP_EVAL if self.is_eval else self.HOST_CAP)
         if getattr(self, "_host_meta", None) is None:
             self._host_meta = torch.empty(2 * B + 1, dtype=torch.int32).pin_memory()
             self._host_boxes = torch.empty((B, hc, 7), dtype=torch.float32).pin_memory()
