@@ -101,6 +101,12 @@ int yv3_conv0(const float* x_nchw, const float* w_tap_major, const float* alpha,
 int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
                    const void* w1_packed, const float* alpha1, const float* beta1, void* y,
                    int B, int H, int W, int* flags, void* stream);
+/* The same for YV3_BF16: the first layer exactly as yv3_conv0(..., YV3_BF16) computes it (fp16 hi+lo matrix-core arithmetic, rounded
+ * to bf16), w1_packed from yv3_pack_conv_weight(..., YV3_BF16), y = one bf16 plane [B,H/2,W/2,64].  Bit-identical to yv3_conv0
+ * followed by yv3_conv2d in YV3_BF16. */
+int yv3_conv_front_bf16(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
+                        const void* w1_packed, const float* alpha1, const float* beta1, void* y,
+                        int B, int H, int W, int* flags, void* stream);
 
 /* The first residual block in one launch (YV3_F32_F16X2 only): feature.mlist.2 = res_layer(64) (darknet.py:46-53),
  * y = x + conv_bn_relu(32,64,3)(conv_bn_relu(64,32,1)(x)), the 32-channel intermediate kept on chip.  Bit-identical to the two

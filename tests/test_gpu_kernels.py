@@ -476,8 +476,9 @@ def test_plain_resize_vs_oracle():
 
 
 
+@pytest.mark.parametrize("mode", [_ffi.F32H2, _ffi.BF16])
 @pytest.mark.parametrize("B,H,W", [(2, 416, 416), (1, 608, 608), (3, 320, 480), (2, 96, 64), (5, 32, 32)])
-def test_fused_front_equals_two_launches_bitwise(B, H, W):
+def test_fused_front_equals_two_launches_bitwise(B, H, W, mode):
     """csrc/conv_front.hip (feature.mlist.0 + feature.mlist.1 in one launch, the first layer's activation kept in LDS) writes
     BIT FOR BIT what yv3_conv0 followed by yv3_conv2d writes (same products, same order), on square / non-square / tiny
     inputs incl. all four image borders; whole-net detections are therefore identical too; saturation is still reported."""
@@ -487,7 +488,8 @@ def test_fused_front_equals_two_launches_bitwise(B, H, W):
     assert WeightManager(net).load_stream(stream) == stream.size
     net = net.cuda()
     x = torch.from_numpy(synth.images(B, max(H, W), 7)[:, :, :H, :W].copy()).cuda()
-    eng = net.engine(_ffi.F32H2)
+    net.math_mode = mode
+    eng = net.engine(mode)
     outs, dets = [], []
     for fused in (False, True):
         eng.fuse_front, eng._plans = fused, {}
@@ -498,10 +500,10 @@ def test_fused_front_equals_two_launches_bitwise(B, H, W):
             dets.append(d.clone())
         finally:
             eng.fuse_front, eng._plans = True, {}
-    assert outs[0].shape == (2, B, H // 2, W // 2, 64)
+    assert outs[0].shape == (2 if mode == _ffi.F32H2 else 1, B, H // 2, W // 2, 64)
     assert torch.equal(outs[0], outs[1]), "%d elements differ" % int((outs[0] != outs[1]).sum())
     assert torch.equal(dets[0], dets[1])
-    with pytest.raises(_ffi.Yv3Error, match="fp16 range"):
+    with pytest.raises(_ffi.Yv3Error, match="fp16 range|fp16 matrix cores"):
         net.forward_cat(x * 1e4)                               # |x| * 16 leaves the fp16 range of the first layer's operands
 
 

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "yv3_merge_planes": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p]),
     "yv3_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "yv3_conv_front": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "yv3_conv_front_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "yv3_res_block64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "yv3_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "yv3_conv2d_sequence": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),

@@ -33,10 +33,15 @@ constexpr int FP_ROWS = 2 * FT_R + 3, FP_COLS = 2 * FT_C + 3;   // input patch 1
 constexpr int FP_PITCH = 36, FP_CH = FP_ROWS * FP_PITCH;  // floats
 constexpr int FA_RP = 18, FA_PB = (2 * FT_R + 1) * FA_RP; // image row pitch (pixels), parity block (306 pixels)
 constexpr int FA_PLANE = 2 * FA_PB * ROWB;                // 39 168 bytes per plane
-constexpr int FW_CHUNK = 2 * 64 * ROWB;                   // packed weights per tap: 2 planes x 64 rows x 64 B
-constexpr int FW_BYTES = 9 * FW_CHUNK;                    // 73 728
-constexpr int F_A_OFF = 0, F_W_OFF = 2 * FA_PLANE, F_P_OFF = F_W_OFF + FW_BYTES;
-constexpr int F_LDS = F_P_OFF + 3 * FP_CH * 4;            // 160 272
+constexpr int F_A_OFF = 0;
+// NP = planes of the second layer's operands / of the output: 2 = fp16 hi + lo (YV3_F32_F16X2), 1 = bf16 (YV3_BF16: the first
+// layer is computed exactly as in the fp16-plane mode -- conv0.hip's conv0_mfma_kernel<true> -- and rounded to bf16)
+template <int NP> struct FrontGeo {
+    static constexpr int FW_CHUNK = NP * 64 * ROWB;           // packed weights per tap: NP planes x 64 rows x 64 B
+    static constexpr int FW_BYTES = 9 * FW_CHUNK;             // 73 728 (NP = 2)
+    static constexpr int F_W_OFF = NP * FA_PLANE, F_P_OFF = F_W_OFF + FW_BYTES;
+    static constexpr int F_LDS = F_P_OFF + 3 * FP_CH * 4;     // 160 272 (NP = 2), 84 240 (NP = 1)
+};
 constexpr int F_EP = 32 + 4;                              // floats per row of a wave's epilogue transpose tile
 
 typedef _Float16 fh16x8 __attribute__((ext_vector_type(8)));
@@ -67,7 +72,10 @@ struct FrontParams {
     int* flags;
 };
 
+template <int NP>
 __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
+    constexpr int FW_CHUNK = FrontGeo<NP>::FW_CHUNK, FW_BYTES = FrontGeo<NP>::FW_BYTES, F_W_OFF = FrontGeo<NP>::F_W_OFF,
+                  F_P_OFF = FrontGeo<NP>::F_P_OFF;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned* const patch = reinterpret_cast<unsigned*>(lds + F_P_OFF);      // each element: fp16 hi | fp16 lo << 16 of 16 * x
     const int tid = threadIdx.x, lane = tid & 63;
@@ -248,19 +256,25 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
                 for (int q = 0; q < 8; ++q) {
                     float t0 = fmaf(acc[n][2 * q], al0[2 * q], be0[2 * q]), t1 = fmaf(acc[n][2 * q + 1], al0[2 * q + 1], be0[2 * q + 1]);
                     t0 = __builtin_fmaxf(t0, 0.1f * t0); t1 = __builtin_fmaxf(t1, 0.1f * t1);      // LeakyReLU(0.1)
-                    const ff32x2 a = {t0, t1};
-                    const fh16x2 h = __builtin_convertvector(a, fh16x2);
-                    const fh16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, ff32x2), fh16x2);
-                    qh[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, h) : 0u;  // outside the image: the second conv's zero padding
-                    ql[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, l) : 0u;
+                    if constexpr (NP == 2) {
+                        const ff32x2 a = {t0, t1};
+                        const fh16x2 h = __builtin_convertvector(a, fh16x2);
+                        const fh16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, ff32x2), fh16x2);
+                        qh[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, h) : 0u;  // outside the image: the second conv's zero padding
+                        ql[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, l) : 0u;
+                    } else {                                                               // bf16, round to nearest even (conv0.hip: yv3_f2bf)
+                        qh[q >> 2][q & 3] = inimg ? ((unsigned)yv3_f2bf(t0) | ((unsigned)yv3_f2bf(t1) << 16)) : 0u;
+                    }
                 }
                 if (gimg[i] >= 0) {
                     const int sw = gimg[i] >> 20;
                     unsigned char* d = lds + (gimg[i] & 0xfffff);
                     *reinterpret_cast<u32x4*>(d + ((lhi ^ sw) * 16)) = qh[0];                   // channels 8*lhi .. +7
                     *reinterpret_cast<u32x4*>(d + (((2 + lhi) ^ sw) * 16)) = qh[1];             // channels 16 + 8*lhi .. +7
-                    *reinterpret_cast<u32x4*>(d + FA_PLANE + ((lhi ^ sw) * 16)) = ql[0];
-                    *reinterpret_cast<u32x4*>(d + FA_PLANE + (((2 + lhi) ^ sw) * 16)) = ql[1];
+                    if constexpr (NP == 2) {
+                        *reinterpret_cast<u32x4*>(d + FA_PLANE + ((lhi ^ sw) * 16)) = ql[0];
+                        *reinterpret_cast<u32x4*>(d + FA_PLANE + (((2 + lhi) ^ sw) * 16)) = ql[1];
+                    }
                 }
             }
         };
@@ -288,13 +302,13 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
             const int aoff = F_A_OFF + (kh * FA_RP + (kw & 1) * FA_PB) * ROWB;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8v wf[2], xf[2];
+                bf16x8v wf[NP], xf[NP];
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
+                for (int pl = 0; pl < NP; ++pl) {
                     wf[pl] = *reinterpret_cast<const bf16x8v*>(lds + wa[ks] + tap * FW_CHUNK + pl * (64 * ROWB));
                     xf[pl] = *reinterpret_cast<const bf16x8v*>(lds + aoff + xa[ks][kw >> 1] + pl * FA_PLANE);
                 }
-                acc2 = mfma_unit<2>(wf, xf, acc2);
+                acc2 = mfma_unit<NP>(wf, xf, acc2);
             }
         }
         FTL(3);
@@ -324,19 +338,26 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(tl + r * F_EP + cg);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(tl + r * F_EP + cg + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-            for (int h = 0; h < 4; ++h) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
-            u32x4 qh, ql;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);
-                v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
-                qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
-                ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
-            }
             u16* yo = p.y + m * 64 + wn * 32 + cg;
-            *reinterpret_cast<u32x4*>(yo) = qh;
-            *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
+                u32x4 qh, ql;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);
+                    v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
+                    qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
+                    ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
+                }
+                *reinterpret_cast<u32x4*>(yo) = qh;
+                *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
+            } else {                                                    // one bf16 plane, as conv_planes_common.h's epilogue (PlaneOps<1>::pack2)
+                u32x4 qb;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) qb[h] = PlaneOps<1>::pack2(v[2 * h], v[2 * h + 1]);
+                *reinterpret_cast<u32x4*>(yo) = qb;
+            }
         }
         FTL(4);
     }
@@ -352,9 +373,10 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
 
 }  // namespace
 
-extern "C" int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
-                              const void* w1_packed, const float* alpha1, const float* beta1, void* y,
-                              int B, int H, int W, int* flags, void* stream) {
+template <int NP>
+static int conv_front_launch(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
+                             const void* w1_packed, const float* alpha1, const float* beta1, void* y,
+                             int B, int H, int W, int* flags, void* stream) {
     if (!x_nchw || !w0_tap_major || !alpha0 || !beta0 || !w1_packed || !alpha1 || !beta1 || !y || B <= 0 || H <= 0 || W <= 0)
         return YV3_EINVAL;
     if ((H % (2 * FT_R)) || (W % (2 * FT_C))) return YV3_ESHAPE;          // whole 8 x 16 output tiles only (network inputs are multiples of 32)
@@ -368,10 +390,22 @@ extern "C" int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, co
     if (total > 0x7fffffffLL) return YV3_ESHAPE;
     p.total = (int)total;
     p.flags = flags;
-    static_assert(F_LDS <= 160 * 1024, "LDS budget");
+    static_assert(FrontGeo<NP>::F_LDS <= 160 * 1024, "LDS budget");
     const int ncu = yv3_num_cu();
     const int grid = p.total < ncu ? p.total : ncu;                      // persistent: one workgroup per CU
-    hipLaunchKernelGGL(conv_front_kernel, dim3(grid), dim3(512), F_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_front_kernel<NP>, dim3(grid), dim3(512), FrontGeo<NP>::F_LDS, (hipStream_t)stream, p);
     YV3_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
+                              const void* w1_packed, const float* alpha1, const float* beta1, void* y,
+                              int B, int H, int W, int* flags, void* stream) {
+    return conv_front_launch<2>(x_nchw, w0_tap_major, alpha0, beta0, w1_packed, alpha1, beta1, y, B, H, W, flags, stream);
+}
+
+extern "C" int yv3_conv_front_bf16(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
+                                   const void* w1_packed, const float* alpha1, const float* beta1, void* y,
+                                   int B, int H, int W, int* flags, void* stream) {
+    return conv_front_launch<1>(x_nchw, w0_tap_major, alpha0, beta0, w1_packed, alpha1, beta1, y, B, H, W, flags, stream);
 }

@@ -298,9 +298,9 @@ class Plan:
         ncu = ncu & ~7 if ncu >= 8 else 256
         # fp16-plane mode: feature.mlist.0 + feature.mlist.1 run as ONE launch (csrc/conv_front.hip); the first layer's
         # [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
-        self.fused_front = bool(engine.fuse_front and dt == F32H2)
+        self.fused_front = bool(engine.fuse_front and dt in (F32H2, BF16))
         # ... and the first residual block (feature.mlist.2: 1x1 64->32 + 3x3 32->64 + add) as one more (csrc/conv_res64.hip)
-        self.fused_res64 = bool(self.fused_front and engine.fuse_res64)
+        self.fused_res64 = bool(self.fused_front and engine.fuse_res64 and dt == F32H2)
         self.first_desc = 3 if self.fused_res64 else (1 if self.fused_front else 0)
 
         def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
@@ -520,7 +520,8 @@ class Engine:
         if not plan.fused_front:
             return self.run_conv0(plan, x)
         p0, p1, d1 = self.packed[0], self.packed[1], plan.descs[0]
-        _ffi.check(_ffi.lib().yv3_conv_front(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
+        front = _ffi.lib().yv3_conv_front if self.dtype == F32H2 else _ffi.lib().yv3_conv_front_bf16
+        _ffi.check(front(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
                                              p1.w.data_ptr(), p1.alpha.data_ptr(), p1.beta.data_ptr(), d1.y,
                                              plan.B, plan.H, plan.W, plan.flags.data_ptr(), _ffi.stream_ptr()), "yv3_conv_front")
         if plan.fused_res64:
