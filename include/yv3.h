@@ -116,6 +116,11 @@ int yv3_conv_front_bf16(const float* x_nchw, const float* w0_tap_major, const fl
 int yv3_res_block64(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
                     const void* w2_packed, const float* alpha2, const float* beta2, void* y,
                     int B, int H, int W, int* flags, void* stream);
+/* The same for YV3_BF16 (x, y: one bf16 plane [B,H,W,64]; weights from yv3_pack_conv_weight(..., YV3_BF16)); bit-identical to
+ * the two yv3_conv2d launches in YV3_BF16. */
+int yv3_res_block64_bf16(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
+                         const void* w2_packed, const float* alpha2, const float* beta2, void* y,
+                         int B, int H, int W, int* flags, void* stream);
 
 typedef struct yv3_conv_desc {
     const void*  x;         /* NHWC [B,H,W,cin] -- or, when cin_up > 0, the LOW-resolution map

@@ -508,8 +508,9 @@ def test_fused_front_equals_two_launches_bitwise(B, H, W, mode):
 
 
 
+@pytest.mark.parametrize("mode", [_ffi.F32H2, _ffi.BF16])
 @pytest.mark.parametrize("B,H,W", [(2, 416, 416), (1, 608, 608), (3, 320, 480), (2, 96, 64), (5, 32, 32)])
-def test_fused_res64_equals_two_launches_bitwise(B, H, W):
+def test_fused_res64_equals_two_launches_bitwise(B, H, W, mode):
     """csrc/conv_res64.hip (feature.mlist.2 = 1x1 64->32 + 3x3 32->64 + residual add in one launch, the 32-channel map kept
     in LDS) writes BIT FOR BIT what the two yv3_conv2d launches write, incl. all image borders; whole-net detections equal."""
     from yolo_v3_amd import YoloNet, WeightManager
@@ -518,7 +519,8 @@ def test_fused_res64_equals_two_launches_bitwise(B, H, W):
     assert WeightManager(net).load_stream(stream) == stream.size
     net = net.cuda()
     x = torch.from_numpy(synth.images(B, max(H, W), 8)[:, :, :H, :W].copy()).cuda()
-    eng = net.engine(_ffi.F32H2)
+    net.math_mode = mode
+    eng = net.engine(mode)
     outs, dets = [], []
     for fused in (False, True):
         eng.fuse_res64, eng._plans = fused, {}
@@ -529,7 +531,7 @@ def test_fused_res64_equals_two_launches_bitwise(B, H, W):
             dets.append(d.clone())
         finally:
             eng.fuse_res64, eng._plans = True, {}
-    assert outs[0].shape == (2, B, H // 2, W // 2, 64)
+    assert outs[0].shape == (2 if mode == _ffi.F32H2 else 1, B, H // 2, W // 2, 64)
     assert torch.equal(outs[0], outs[1]), "%d elements differ" % int((outs[0] != outs[1]).sum())
     assert torch.equal(dets[0], dets[1])
 

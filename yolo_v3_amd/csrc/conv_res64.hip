@@ -19,14 +19,17 @@ namespace {
 constexpr int RT_R = 8, RT_C = 16;                        // output tile (rows x cols)
 constexpr int RR_COLS = RT_C + 2, RR_PX = (RT_R + 2) * RR_COLS;   // region 10 x 18 = 180 pixels
 constexpr int RR_ROWS32 = 192;                            // padded to 6 MFMA column blocks
-constexpr int RX_PLANE = RR_ROWS32 * ROWB;                // x region: [2 chunks][2 planes][192 rows][64 B]
-constexpr int RX_CHUNK = 2 * RX_PLANE, RX_BYTES = 2 * RX_CHUNK;   // 49 152
+constexpr int RX_PLANE = RR_ROWS32 * ROWB;                // x region: [2 chunks][NP planes][192 rows][64 B]
 constexpr int RI_RP = 20;                                 // image pitch (pixels per row)
 constexpr int RI_PLANE = (RT_R + 2) * RI_RP * ROWB;       // 12 800
 constexpr int RE_BYTES = 8 * 32 * 36 * 4;                 // epilogue transposes (re-use the image's space + slack): 36 864
-constexpr int RW_BYTES = 9 * 2 * 64 * ROWB;               // 73 728
-constexpr int R_X_OFF = 0, R_I_OFF = RX_BYTES, R_W_OFF = R_I_OFF + RE_BYTES, R_LDS = R_W_OFF + RW_BYTES;   // 159 744
-static_assert(2 * RI_PLANE <= RE_BYTES && R_LDS <= 160 * 1024, "LDS budget");
+// NP = planes of the tensors: 2 = fp16 hi + lo (YV3_F32_F16X2), 1 = bf16 (YV3_BF16)
+template <int NP> struct ResGeo {
+    static constexpr int RX_CHUNK = NP * RX_PLANE, RX_BYTES = 2 * RX_CHUNK;      // 49 152 (NP = 2)
+    static constexpr int RW_BYTES = 9 * NP * 64 * ROWB;                          // 73 728 (NP = 2)
+    static constexpr int R_X_OFF = 0, R_I_OFF = RX_BYTES, R_W_OFF = R_I_OFF + RE_BYTES, R_LDS = R_W_OFF + RW_BYTES;   // 159 744 (NP = 2)
+    static_assert(NP * RI_PLANE <= RE_BYTES && R_LDS <= 160 * 1024, "LDS budget");
+};
 constexpr int R_EP = 36;
 
 struct Res64Params {
@@ -39,7 +42,10 @@ struct Res64Params {
     int* flags;
 };
 
+template <int NP>
 __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
+    constexpr int RX_CHUNK = ResGeo<NP>::RX_CHUNK, RW_BYTES = ResGeo<NP>::RW_BYTES, R_X_OFF = ResGeo<NP>::R_X_OFF,
+                  R_I_OFF = ResGeo<NP>::R_I_OFF, R_W_OFF = ResGeo<NP>::R_W_OFF;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,14 +56,14 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
     for (int pc = wid; pc < RW_BYTES / 1024; pc += 8)
         __builtin_amdgcn_global_load_lds(GPTR(p.w2 + pc * 512 + lane * 8), LPTR(lds + R_W_OFF + pc * 1024), 16, 0, 0);
     // ---- 1x1 weights: this lane's fragments, resident in registers ([chunk][plane][row 32][slot ^ swz][8] packed image)
-    bf16x8v wf1[2][2][2];
+    bf16x8v wf1[2][2][NP];
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                wf1[kc][ks][pl] = *reinterpret_cast<const bf16x8v*>(p.w1 + ((kc * 2 + pl) * 32 + l31) * PBK + (((ks * 2 + lhi) ^ swz(l31)) * 8));
+            for (int pl = 0; pl < NP; ++pl)
+                wf1[kc][ks][pl] = *reinterpret_cast<const bf16x8v*>(p.w1 + ((kc * NP + pl) * 32 + l31) * PBK + (((ks * 2 + lhi) ^ swz(l31)) * 8));
     f32x4 alv1[4], bev1[4], alv2[4], bev2[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -67,15 +73,16 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
         bev2[g] = *reinterpret_cast<const f32x4*>(p.beta2 + wn * 32 + 8 * g + 4 * lhi);
     }
 
-    // ---- x-region DMA: 48 wave instructions per tile (2 chunks x 2 planes x 12 groups of 16 rows); this wave issues
+    // ---- x-region DMA: 24 NP wave instructions per tile (2 chunks x NP planes x 12 groups of 16 rows); this wave issues
     // i = wid + 8k.  Per lane: region pixel of its row, source swizzle (undone by the fragment reads), all tile-independent.
+    constexpr int DK = 3 * NP;                            // instructions per wave
     const int sslot = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-    int drr[6], dcc[6];
-    long long dsrc[6];
+    int drr[DK], dcc[DK];
+    long long dsrc[DK];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < DK; ++k) {
         const int i = wid + 8 * k;
-        const int kc = i / 24, pl = (i / 12) & 1, grp = i % 12;
+        const int kc = i / (12 * NP), pl = (i / 12) % NP, grp = i % 12;
         const int row = grp * 16 + (lane >> 2);
         drr[k] = row < RR_PX ? row / RR_COLS : -100;      // rows 180..191: never inside the picture -> zero page
         dcc[k] = row - (row / RR_COLS) * RR_COLS;
@@ -86,9 +93,9 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
         const int rem = tile - b * (p.tiles_x * p.tiles_y);
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < DK; ++k) {
             const int i = wid + 8 * k;
-            const int kc = i / 24, pl = (i / 12) & 1, grp = i % 12;
+            const int kc = i / (12 * NP), pl = (i / 12) % NP, grp = i % 12;
             const int gy = RT_R * ty - 1 + drr[k], gx = RT_C * tx - 1 + dcc[k];
             const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const u16* src = ok ? p.x + dsrc[k] + (((long long)b * p.H + gy) * p.W + gx) * 64 : g_zero_page;
@@ -149,10 +156,10 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8v xf[2];
+                    bf16x8v xf[NP];
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) xf[pl] = *reinterpret_cast<const bf16x8v*>(lds + x1a[ks] + kc * RX_CHUNK + pl * RX_PLANE);
-                    acc = mfma_unit<2>(wf1[kc][ks], xf, acc);
+                    for (int pl = 0; pl < NP; ++pl) xf[pl] = *reinterpret_cast<const bf16x8v*>(lds + x1a[ks] + kc * RX_CHUNK + pl * RX_PLANE);
+                    acc = mfma_unit<NP>(wf1[kc][ks], xf, acc);
                 }
             const int gy = r0 - 1 + rrr, gx = c0 - 1 + rcc;
             const bool inimg = rlive && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
@@ -163,19 +170,23 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
                 for (int q = 0; q < 4; ++q) {
                     const float t = fmaf(acc[4 * g + q], alv1[g][q], bev1[g][q]);
                     v[q] = __builtin_fmaxf(t, 0.1f * t);
-                    amax = __builtin_fmaxf(amax, __builtin_fabsf(v[q]));
-                    v[q] = __builtin_amdgcn_fmed3f(v[q], -65504.f, 65504.f);
+                    if constexpr (NP == 2) {
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(v[q]));
+                        v[q] = __builtin_amdgcn_fmed3f(v[q], -65504.f, 65504.f);
+                    }
                 }
                 u32x2 qh, ql;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
-                    ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
+                    if constexpr (NP == 2) {
+                        qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
+                        ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
+                    } else { qh[h] = PlaneOps<1>::pack2(v[2 * h], v[2 * h + 1]); ql[h] = 0u; }
                     if (!inimg) { qh[h] = 0u; ql[h] = 0u; }       // outside the picture: the 3x3 conv's zero padding
                 }
                 if (rlive) {                                      // channels 8g + 4*lhi .. +3: 8 bytes of slot g
                     *reinterpret_cast<u32x2*>(lds + rimg + ((g ^ rsw) * 16) + lhi * 8) = qh;
-                    *reinterpret_cast<u32x2*>(lds + rimg + RI_PLANE + ((g ^ rsw) * 16) + lhi * 8) = ql;
+                    if constexpr (NP == 2) *reinterpret_cast<u32x2*>(lds + rimg + RI_PLANE + ((g ^ rsw) * 16) + lhi * 8) = ql;
                 }
             }
         }
@@ -185,14 +196,14 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
         if (tile + (int)gridDim.x < p.total) x_dma(tile + gridDim.x);          // lands during steps 3-4
 
         // residual rows of this wave's 32 x 32 output tile (L2-warm: the region DMA just read them), requested before the 3x3
-        u32x4 rres[2][2];
+        u32x4 rres[2][NP];
         long long orow[2];
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int t = wm * 32 + ps * 16 + (lane >> 2);
             orow[ps] = (((long long)b * p.H + r0 + (t >> 4)) * p.W + c0 + (t & 15)) * 64 + wn * 32 + (lane & 3) * 8;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) rres[ps][pl] = *reinterpret_cast<const u32x4*>(p.x + pl * p.ps + orow[ps]);
+            for (int pl = 0; pl < NP; ++pl) rres[ps][pl] = *reinterpret_cast<const u32x4*>(p.x + pl * p.ps + orow[ps]);
         }
 
         // ---- 3. 3x3 conv out of LDS
@@ -204,13 +215,13 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
             const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8v wf[2], xf[2];
+                bf16x8v wf[NP], xf[NP];
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    wf[pl] = *reinterpret_cast<const bf16x8v*>(lds + wa[ks] + tap * (2 * 64 * ROWB) + pl * (64 * ROWB));
+                for (int pl = 0; pl < NP; ++pl) {
+                    wf[pl] = *reinterpret_cast<const bf16x8v*>(lds + wa[ks] + tap * (NP * 64 * ROWB) + pl * (64 * ROWB));
                     xf[pl] = *reinterpret_cast<const bf16x8v*>(lds + xa[ks][kw] + kh * (RI_RP * ROWB) + pl * RI_PLANE);
                 }
-                acc2 = mfma_unit<2>(wf, xf, acc2);
+                acc2 = mfma_unit<NP>(wf, xf, acc2);
             }
         }
         RTL(3);
@@ -241,21 +252,28 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(tl + r * R_EP + cg + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                for (int h = 0; h < 4; ++h) { v[2 * h] += PlaneOps<2>::lo(rres[ps][pl][h]); v[2 * h + 1] += PlaneOps<2>::hi(rres[ps][pl][h]); }
+                for (int h = 0; h < 4; ++h) { v[2 * h] += PlaneOps<NP>::lo(rres[ps][pl][h]); v[2 * h + 1] += PlaneOps<NP>::hi(rres[ps][pl][h]); }
+            if constexpr (NP == 2) {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
-            u32x4 qh, ql;
+                for (int h = 0; h < 4; ++h) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
+                u32x4 qh, ql;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);
-                v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
-                qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
-                ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
+                for (int h = 0; h < 4; ++h) {
+                    v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);
+                    v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
+                    qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
+                    ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
+                }
+                *reinterpret_cast<u32x4*>(p.y + orow[ps]) = qh;
+                *reinterpret_cast<u32x4*>(p.y + p.ps + orow[ps]) = ql;
+            } else {
+                u32x4 qb;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) qb[h] = PlaneOps<1>::pack2(v[2 * h], v[2 * h + 1]);
+                *reinterpret_cast<u32x4*>(p.y + orow[ps]) = qb;
             }
-            *reinterpret_cast<u32x4*>(p.y + orow[ps]) = qh;
-            *reinterpret_cast<u32x4*>(p.y + p.ps + orow[ps]) = ql;
         }
         RTL(4);
     }
@@ -271,9 +289,10 @@ __global__ __launch_bounds__(512) void conv_res64_kernel(const Res64Params p) {
 
 }  // namespace
 
-extern "C" int yv3_res_block64(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
-                               const void* w2_packed, const float* alpha2, const float* beta2, void* y,
-                               int B, int H, int W, int* flags, void* stream) {
+template <int NP>
+static int res_block64_launch(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
+                              const void* w2_packed, const float* alpha2, const float* beta2, void* y,
+                              int B, int H, int W, int* flags, void* stream) {
     if (!x || !w1_packed || !alpha1 || !beta1 || !w2_packed || !alpha2 || !beta2 || !y || B <= 0 || H <= 0 || W <= 0) return YV3_EINVAL;
     if ((H % RT_R) || (W % RT_C)) return YV3_ESHAPE;                    // whole 8 x 16 tiles only
     Res64Params p;
@@ -288,7 +307,19 @@ extern "C" int yv3_res_block64(const void* x, const void* w1_packed, const float
     p.flags = flags;
     const int ncu = yv3_num_cu();
     const int grid = p.total < ncu ? p.total : ncu;                    // persistent: one workgroup per CU
-    hipLaunchKernelGGL(conv_res64_kernel, dim3(grid), dim3(512), R_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_res64_kernel<NP>, dim3(grid), dim3(512), ResGeo<NP>::R_LDS, (hipStream_t)stream, p);
     YV3_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int yv3_res_block64(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
+                               const void* w2_packed, const float* alpha2, const float* beta2, void* y,
+                               int B, int H, int W, int* flags, void* stream) {
+    return res_block64_launch<2>(x, w1_packed, alpha1, beta1, w2_packed, alpha2, beta2, y, B, H, W, flags, stream);
+}
+
+extern "C" int yv3_res_block64_bf16(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
+                                    const void* w2_packed, const float* alpha2, const float* beta2, void* y,
+                                    int B, int H, int W, int* flags, void* stream) {
+    return res_block64_launch<1>(x, w1_packed, alpha1, beta1, w2_packed, alpha2, beta2, y, B, H, W, flags, stream);
 }

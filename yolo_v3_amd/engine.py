@@ -300,7 +300,7 @@ class Plan:
         # [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
         self.fused_front = bool(engine.fuse_front and dt in (F32H2, BF16))
         # ... and the first residual block (feature.mlist.2: 1x1 64->32 + 3x3 32->64 + add) as one more (csrc/conv_res64.hip)
-        self.fused_res64 = bool(self.fused_front and engine.fuse_res64 and dt == F32H2)
+        self.fused_res64 = bool(self.fused_front and engine.fuse_res64)
         self.first_desc = 3 if self.fused_res64 else (1 if self.fused_front else 0)
 
         def conv(i, x, h, w, residual=None, x2=None, cin_up=0, out_dtype=None):
@@ -526,7 +526,8 @@ class Engine:
                                              plan.B, plan.H, plan.W, plan.flags.data_ptr(), _ffi.stream_ptr()), "yv3_conv_front")
         if plan.fused_res64:
             p2, p3, d3 = self.packed[2], self.packed[3], plan.descs[2]
-            _ffi.check(_ffi.lib().yv3_res_block64(d1.y, p2.w.data_ptr(), p2.alpha.data_ptr(), p2.beta.data_ptr(),
+            res = _ffi.lib().yv3_res_block64 if self.dtype == F32H2 else _ffi.lib().yv3_res_block64_bf16
+            _ffi.check(res(d1.y, p2.w.data_ptr(), p2.alpha.data_ptr(), p2.beta.data_ptr(),
                                                   p3.w.data_ptr(), p3.alpha.data_ptr(), p3.beta.data_ptr(), d3.y,
                                                   plan.B, plan.H // 2, plan.W // 2, plan.flags.data_ptr(), _ffi.stream_ptr()),
                        "yv3_res_block64")
