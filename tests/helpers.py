@@ -193,3 +193,11 @@ def state_dict_to_stream(sd, num_class=80):
         keys = oc._cbr_keys(prefix) if has_bn else [prefix + ".bias", prefix + ".weight"]
         parts += [sd[key].detach().float().numpy().ravel() for key in keys]
     return np.concatenate(parts).astype(np.float32)
+
+
+def detector_dets(net):
+    """The detections tensor of the detector ``detect()`` / ``detect_sharded()`` used last (an LRU cache on the net): the
+    "identical detections" for bit-exact post-processing checks.  (``net.forward_cat`` runs the one-lane plan of the whole
+    batch; a Detector may run two lanes of half the batch, for which the library may choose another form of a layer --
+    Winograd or direct, stream-K or not -- so its detections can differ from forward_cat's in the last bits.)"""
+    return list(net._detectors.values())[-1].dets

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from oracle import oracle_cpu as oc
 from oracle.boxdelta import boxes_delta
 from yolo_v3_amd import synth, detect, postprocessing, YoloNet, WeightManager, _ffi, engine
-from tests.helpers import (TOL, assert_close_rel, rel_err, load_sw1_net, teacher_forced_layers, bf16_ulp,
+from tests.helpers import (TOL, assert_close_rel, rel_err, load_sw1_net, teacher_forced_layers, bf16_ulp, detector_dets,
                            hostile_state_dict, state_dict_to_stream)
 
 pytestmark = pytest.mark.gpu
@@ -144,7 +144,7 @@ def test_config5_dense_full_network_vs_oracle():
     ncand = ((got[..., 5:] * got[..., 4:5]).amax(-1) > 0.5).sum(1)
     assert int(ncand.min()) >= 5000, ncand.tolist()
     res = detect(net, x.cuda(), 80, 0.5, 0.4)
-    exact = oc.postprocess(got, 80, 0.5, 0.4)                    # same detections -> decisions must be identical
+    exact = oc.postprocess(detector_dets(net).cpu(), 80, 0.5, 0.4)   # same detections -> decisions must be identical
     for a, b in zip(res, exact):
         assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b)
     want = oc.postprocess(ref, 80, 0.5, 0.4)
@@ -364,7 +364,7 @@ def test_eval_mode_at_reference_thresholds(golden_dir):
         dets = net.forward_cat(x.cuda())
     assert_close_rel(dets[:, g["rows"]].cpu(), g["dets_rows"], TOL, "SW-eval detections")
     res = detect(net, x.cuda(), 80, 0.005, 0.45, is_eval=True)
-    exact = oc.postprocess(dets.cpu(), 80, 0.005, 0.45, True, True)
+    exact = oc.postprocess(detector_dets(net).cpu(), 80, 0.005, 0.45, True, True)
     for a, b in zip(res, exact):
         assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b)
     want = [torch.from_numpy(g["boxes%d" % i]) for i in range(B)]

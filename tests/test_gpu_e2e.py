@@ -9,7 +9,7 @@ import torch
 
 from oracle import oracle_cpu as oc
 from yolo_v3_amd import synth, detect, postprocessing, Detector, _ffi
-from tests.helpers import TOL, assert_close_rel, match_boxes, check_result_convention, load_sw1_net
+from tests.helpers import TOL, assert_close_rel, match_boxes, check_result_convention, load_sw1_net, detector_dets
 
 pytestmark = pytest.mark.gpu
 
@@ -82,15 +82,13 @@ def test_decisions_exact_on_identical_detections(net):
     """Filter / sort / NMS are integer-and-compare work: on the GPU's own detections the HIP
     post-processing must equal the oracle's bit for bit (B=4, 416)."""
     x = torch.from_numpy(synth.images(4, 416, 4242)).cuda()
-    with torch.no_grad():
-        dets = net.forward_cat(x)
-    ref = oc.postprocess(dets.cpu(), 80, 0.5, 0.4)
     res = detect(net, x)
+    ref = oc.postprocess(detector_dets(net).cpu(), 80, 0.5, 0.4)
     check_result_convention(res, ref)
     for r, e in zip(res, ref):
         assert torch.equal(r, e)
-    ref = oc.postprocess(dets.cpu(), 80, 0.3, 0.45, True, True)
     res = detect(net, x, 80, 0.3, 0.45, is_eval=True)
+    ref = oc.postprocess(detector_dets(net).cpu(), 80, 0.3, 0.45, True, True)
     for r, e in zip(res, ref):
         assert torch.equal(r, e)
 
@@ -262,8 +260,8 @@ def test_other_class_counts_and_sizes(nc, size, mode):
     assert dets.shape == ref.shape == (2, 3 * 21 * (size // 32) ** 2, 5 + nc)
     assert_close_rel(dets.cpu(), ref, TOL, "nc=%d size=%d" % (nc, size))
     thr = 0.3
-    exp = oc.postprocess(dets.cpu(), nc, thr, 0.4)
     got = detect(net, x.cuda(), nc, thr, 0.4)
+    exp = oc.postprocess(detector_dets(net).cpu(), nc, thr, 0.4)
     check_result_convention(got, exp)
     for a, b in zip(got, exp):
         assert torch.equal(a, b)
