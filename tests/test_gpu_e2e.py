@@ -54,9 +54,13 @@ def test_forward_and_boxes_vs_reference_golden(golden_dir, net, name, mode):
     fused = detect(net, x, 80, 0.5, 0.4)
     assert len(res) == len(fused) == int(g[name + "_nres"][0])
     worst = 0.0
+    one_plan = list(net._detectors.values())[-1].lanes == 1      # the detector ran the same one-lane plan as net(x): same bits
     for i, (r, f) in enumerate(zip(res, fused)):
-        assert torch.equal(r, f)
-        worst = max(worst, match_boxes(r, g["%s_boxes%d" % (name, i)], TOL))
+        if one_plan:
+            assert torch.equal(r, f)
+        else:                                                     # (forced YV3_LANES=2 on a tiny batch: another schedule per lane)
+            match_boxes(f, r, TOL)
+        worst = max(worst, match_boxes(r, g["%s_boxes%d" % (name, i)], TOL), match_boxes(f, g["%s_boxes%d" % (name, i)], TOL))
     print("%s mode %d: max detection err %.3g, max box err %.3g" % (name, mode, err, worst))
 
 
