@@ -193,7 +193,7 @@ def test_full_size_properties(net, sw1_stream):
     for a, b in zip(res, res_g):
         assert torch.equal(a, b)
     direct = load_sw1_net(sw1_stream).cuda()
-    direct.winograd = False
+    direct.winograd, direct.stream_k = False, False             # (stream_k None would switch the stream-K schedule on for single images)
     res_d = Detector(direct, 32, 416, 416)(x)
     ref_d = detect(direct, torch.from_numpy(base[:2]).cuda())
     for i in range(2):
