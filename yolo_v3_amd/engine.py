@@ -433,12 +433,24 @@ class Engine:
 
     # -- weights
     def _param_tensors(self):
+        """Every tensor the packed weights depend on, in spec order.  The module objects are resolved once (75
+        ``get_submodule`` path walks cost ~1.4 ms -- per forward, and exposed in every synchronous ``detect()`` call); the
+        tensors themselves are re-read from them each time, so re-assigned parameters are still seen."""
+        mods = self.__dict__.get("_mods")
+        if mods is None:
+            mods = self._mods = [self.net.get_submodule(sp.name) for sp in self.specs]
         out = []
-        for sp in self.specs:
-            w, bn, bias = conv_params(self.net.get_submodule(sp.name))
-            out += [w] if bn is None else [w, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-            if bias is not None:
-                out.append(bias)
+        for m in mods:                               # (straight from the modules' dicts: nn.Module.__getattr__ is slow)
+            if isinstance(m, torch.nn.Conv2d):
+                pr = m._parameters
+                out.append(pr["weight"])
+                if pr["bias"] is not None:
+                    out.append(pr["bias"])
+            else:
+                sub = m._modules
+                bn = sub["bn"]
+                bp, bb = bn._parameters, bn._buffers
+                out += [sub["conv"]._parameters["weight"], bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"]]
         return out
 
     def _signature(self):
