@@ -192,6 +192,85 @@ def test_nms_properties_at_full_size():
     assert torch.equal(res[0], ref[0])
 
 
+def _grid_detections(B, N, seed, ncls=3):
+    """Boxes with even integer extents on an integer grid: IOUs are ratios of small integers, so many pairs sit EXACTLY on a
+    threshold like 0.5, 0.25 or float32(1/3) (strict `>`: not suppressed) or one step beside it."""
+    u = synth.uniform01(seed, 3, B * N * 8).reshape(B, N, 8)
+    d = np.zeros((B, N, 85), dtype=np.float32)
+    d[..., 0] = 40 + np.floor(u[..., 0] * 24)
+    d[..., 1] = 40 + np.floor(u[..., 1] * 24)
+    d[..., 2] = 2 * (1 + np.floor(u[..., 2] * 6))
+    d[..., 3] = 2 * (1 + np.floor(u[..., 3] * 6))
+    d[..., 4] = 0.6 + 0.39 * u[..., 4]
+    d[..., 5:] = 0.01
+    cls = (u[..., 5] * ncls).astype(np.int64) * 11
+    bi, ri = np.meshgrid(np.arange(B), np.arange(N), indexing="ij")
+    d[bi, ri, 5 + cls] = 0.8 + 0.19 * u[..., 6]
+    return d
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.25, float(np.float32(1.0) / np.float32(3.0)), 0.2, 0.6, 0.4])
+def test_nms_pairs_exactly_on_the_threshold(thr):
+    """The mask kernel decides `inter / union > thr` without dividing (exact reformulation, postproc.hip mask_kernel): on integer
+    boxes thousands of pairs have an IOU equal to the threshold or a few ulp away -- every decision must equal the oracle's
+    literal fp32 division + compare (reference utils.py:98-119,177-190)."""
+    dt = torch.from_numpy(_grid_detections(2, 1400, 41))
+    ref = oc.postprocess(dt, 80, 0.5, thr, False, True)
+    res = postprocessing(dt.cuda(), 80, 0.5, thr, False, True)
+    check_result_convention(res, ref)
+    for r, e in zip(res, ref):
+        assert torch.equal(r, e)
+    assert 20 < sum(len(r) for r in res) < 2 * 1400
+
+
+def test_nms_boxes_the_fast_compare_must_not_see():
+    """NaN / infinite / huge coordinates and negative extents among ordinary boxes: tiles holding such a box take the literal
+    IOU path; results equal the oracle bit for bit (NaN IOUs compare false, a NaN self-IOU drops the box, utils.py:182)."""
+    d = _grid_detections(2, 900, 43, ncls=2)
+    d[:, 5::37, 0] = np.nan
+    d[:, 11::41, 2] = np.inf
+    d[:, 17::43, 3] = -6.0                     # negative height: y2 < y1
+    d[:, 23::47, 0] = 3e30
+    d[:, 29::53, 2] = 1e25
+    d[:, 31::59, 2:4] = 0.0                    # zero area
+    dt = torch.from_numpy(d)
+    for thr in (0.4, 0.5):
+        ref = oc.postprocess(dt.clone(), 80, 0.5, thr, False, True)
+        res = postprocessing(dt.cuda(), 80, 0.5, thr, False, True)
+        check_result_convention(res, ref)
+        for r, e in zip(res, ref):
+            assert r.shape == e.shape and np.array_equal(r.numpy(), e.numpy(), equal_nan=True)
+    # thresholds outside the fast compare's range (0, negative, tiny, >= 1) take the literal path everywhere
+    for thr in (0.0, -0.5, 1e-42, 1.0):
+        ref = oc.postprocess(dt.clone(), 80, 0.5, thr, False, True)
+        res = postprocessing(dt.cuda(), 80, 0.5, thr, False, True)
+        for r, e in zip(res, ref):
+            assert r.shape == e.shape and np.array_equal(r.numpy(), e.numpy(), equal_nan=True)
+
+
+def test_nms_long_single_class_segment():
+    """One class with ~6000 candidates in one image (94 mask words, the scan's word pipeline over all its waves) next to an
+    image with none and one with a handful: bit-exact vs the oracle."""
+    N = 6400
+    u = synth.uniform01(47, 1, 3 * N * 8).reshape(3, N, 8)
+    d = np.zeros((3, N, 85), dtype=np.float32)
+    d[..., 0] = 30 + u[..., 0] * 540
+    d[..., 1] = 30 + u[..., 1] * 540
+    d[..., 2] = 20 + u[..., 2] * 70
+    d[..., 3] = 20 + u[..., 3] * 70
+    d[0, :, 4] = 0.55 + 0.44 * u[0, :, 4]
+    d[1, :, 4] = 0.1
+    d[2, :, 4] = np.where(np.arange(N) % 500 == 3, 0.9, 0.1)
+    d[..., 5 + 17] = 0.8 + 0.19 * u[..., 5]
+    dt = torch.from_numpy(d)
+    ref = oc.postprocess(dt, 80, 0.5, 0.4, False, True)
+    res = postprocessing(dt.cuda(), 80, 0.5, 0.4, False, True)
+    check_result_convention(res, ref)
+    for r, e in zip(res, ref):
+        assert torch.equal(r, e)
+    assert len(res[0]) > 300
+
+
 # ----------------------------------------------------------------------------- convolutions
 def _rand_cbr(cin, cout, k, s, seed):
     m = conv_bn_relu(cin, cout, k, s)

@@ -231,3 +231,21 @@ def test_winograd_eligibility_and_geometry():
     assert len(h2) == 18 and all(s.k == 3 and s.stride == 1 and s.cin >= 256 for s in h2)          # 11 x 256->512, 7 x 512->1024
     assert len(f32) == 31 and all(s.cout % 128 == 0 and s.cin >= 64 for s in f32)                  # + 11 x 128->256, 2 x 64->128
     assert not any(engine.wino_eligible(s, _ffi.BF16) or engine.wino_eligible(s, _ffi.F32X3) for s in specs)
+
+
+def test_division_free_iou_compare_is_exact():
+    """csrc/postproc.hip mask_kernel replaces `inter / union > thr` (fp32 division, reference utils.py:116-119,177) by
+    `double(inter) > mid * double(union)`, mid = midpoint of thr and the next float: check the equivalence on the pairs
+    that could break it -- inter within a few ulp of thr * union, for several thresholds."""
+    rng = np.random.default_rng(5)
+    for thr in [0.4, 0.45, 0.5, float(np.float32(1) / np.float32(3)), 0.05, 0.999, 1e-3]:
+        thr = np.float32(thr)
+        mid = 0.5 * (np.float64(thr) + np.float64(np.nextafter(thr, np.float32(np.inf))))
+        union = (rng.random(200000, dtype=np.float32) * np.float32(10) ** rng.integers(-3, 6, 200000).astype(np.float32)).astype(np.float32)
+        union = union[union > 0]
+        inter = (union.astype(np.float64) * np.float64(thr)).astype(np.float32)
+        for step in range(-3, 4):
+            x = inter.copy()
+            for _ in range(abs(step)):
+                x = np.nextafter(x, np.float32(np.inf if step > 0 else -np.inf))
+            assert np.array_equal((x / union) > thr, x.astype(np.float64) > mid * union.astype(np.float64))
