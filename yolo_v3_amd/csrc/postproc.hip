@@ -20,6 +20,7 @@
 //            independent loads
 //   compact  per image prefix sum of keep flags -> out[B,cap,7]
 #include "yv3_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ d
     const int attrib = 5 + C;
     const float* img = dets + (size_t)b * N * attrib;
     u64* kb = keys + (size_t)b * max_cand;
+    float mybest = -INFINITY; int mycls = 0;          // lane L keeps the result of row row0+L (non-eval mode)
     if (row0 < N) {
         const int row = row0 + lane;
         float conf = 0.f;
@@ -113,7 +115,6 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ d
         // `prob`: the caller guarantees cls in [0,1] (sigmoid outputs) => cls*conf <= conf (rounding is
         // monotonic), so only rows with conf > thr can pass and the others are never read.
         u64 todo = __ballot(row < N && (!prob || conf > thr));
-        float mybest = -INFINITY; int mycls = 0;      // lane L keeps the result of row row0+L (non-eval mode)
         if (STAGED && __popcll(todo) >= FILTER_STAGE_MIN) {
             float* stage = reinterpret_cast<float*>(hist + C) + (size_t)(threadIdx.x >> 6) * 32 * attrib;
             const int r = lane & 31, half = lane >> 5;
@@ -240,19 +241,27 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ d
                 }
             }
         }
-        if (!EVAL) {
-            const bool pass = mybest > thr;                             // utils.py:243
-            const u64 pm = __ballot(pass);
-            if (pm) {                                                   // ONE counter atomic per wave
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&counts[b], __popcll(pm));
-                base = __shfl(base, 0);
-                if (pass) {
-                    const int slot = base + __popcll(pm & ((1ull << lane) - 1));
-                    if (slot < max_cand) {
-                        kb[slot] = make_key(mycls, mybest, row);
-                        atomicAdd(&hist[mycls], 1);
-                    }
+    }
+    if (!EVAL) {
+        // ONE counter atomic per workgroup (a dense scene has 356 waves per image with candidates: their same-address atomics
+        // queue up in L2): wave counts -> LDS, thread 0 reserves the block's range, every wave takes its slice
+        __shared__ int wcnt[4], wbase;
+        const int row = row0 + lane, wv = threadIdx.x >> 6;
+        const bool pass = row0 < N && mybest > thr;                     // utils.py:243
+        const u64 pm = __ballot(pass);
+        if (lane == 0) wcnt[wv] = __popcll(pm);
+        __syncthreads();
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (tot) {
+            if (threadIdx.x == 0) wbase = atomicAdd(&counts[b], tot);
+            __syncthreads();
+            if (pass) {
+                int base = wbase;
+                for (int q = 0; q < wv; ++q) base += wcnt[q];
+                const int slot = base + __popcll(pm & ((1ull << lane) - 1));
+                if (slot < max_cand) {
+                    kb[slot] = make_key(mycls, mybest, row);
+                    atomicAdd(&hist[mycls], 1);
                 }
             }
         }
@@ -295,10 +304,12 @@ size_t nms_layout(NmsWs* ws, char* base, int B, int max_n, int C) {
     return off;
 }
 
-// A box the fast IOU test may see: finite, |coordinate| <= 1e18 (areas and their sums stay finite), x2 >= x1, y2 >= y1.
+// A box the fast IOU test may see: finite, |coordinate| <= 1e18 (areas and their sums stay finite), x2 >= x1, y2 >= y1, area 0 or >= 1e-30.
 __device__ inline bool box_tame(const f32x4 b) {
     const float L = 1e18f;
-    return fabsf(b[0]) <= L && fabsf(b[1]) <= L && fabsf(b[2]) <= L && fabsf(b[3]) <= L && b[2] >= b[0] && b[3] >= b[1];
+    const float a = (b[2] - b[0]) * (b[3] - b[1]);       // (a tiny positive area: products in the screen could go denormal)
+    return fabsf(b[0]) <= L && fabsf(b[1]) <= L && fabsf(b[2]) <= L && fabsf(b[3]) <= L && b[2] >= b[0] && b[3] >= b[1] &&
+           (a == 0.f || a >= 1e-30f);
 }
 __device__ inline int2 box_aux(const f32x4 b, int cls) {
     return make_int2(__float_as_int((b[2] - b[0]) * (b[3] - b[1])), cls | (box_tame(b) ? TAME_BIT : 0));
@@ -548,7 +559,7 @@ __device__ inline float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1,
 __device__ inline float vmax0(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
 
 __global__ __launch_bounds__(256) void mask_kernel(const int* __restrict__ counts, int max_cand, NmsWs ws, int max_n, int C,
-                                                   float thr, double mid, int fast_ok) {
+                                                   float thr, double mid, float t2, int fast_ok) {
     __shared__ f32x4 rbox[4][64];
     __shared__ int2 raux[4][64];
     __shared__ int wpart[4];
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(256) void mask_kernel(const int* __restrict__ count
     int ti = tfirst[tj] + (it - pre[tj]);
     const u64 lt = (1ull << lane) - 1ull;
     int cur_tj = -1;
-    f32x4 bj = {0.f, 0.f, 0.f, 0.f}; float aj = 0.f; int cj = -2; bool tame_cols = true;
+    f32x4 bj = {0.f, 0.f, 0.f, 0.f}; float aj = 0.f, sj = 0.f; int cj = -2, cj0 = -2; bool tame_cols = true;
     for (; it < it_end; ++it) {
         const int j = tj * 64 + lane;
         if (cur_tj != tj) {
@@ -607,36 +618,48 @@ __global__ __launch_bounds__(256) void mask_kernel(const int* __restrict__ count
             bj = f32x4{0.f, 0.f, 0.f, 0.f}; aj = 0.f; cj = -2;
             if (j < n) { bj = ws.sbox[base + j]; const int2 a = ws.saux[base + j]; aj = __int_as_float(a.x); cj = a.y; }
             tame_cols = __ballot(j < n && !(cj & TAME_BIT)) == 0;
+            sj = t2 * aj;
+            cj0 = __builtin_amdgcn_readfirstlane(cj);                 // (lane 0 of a column tile is always < n)
         }
         const int i = ti * 64 + lane;
         f32x4 bi = {0.f, 0.f, 0.f, 0.f}; int2 ai = make_int2(0, -1);
         if (i < n) { bi = ws.sbox[base + i]; ai = ws.saux[base + i]; }
         const bool fast = fast_ok && tame_cols && __ballot(i < n && !(ai.y & TAME_BIT)) == 0;
+        // fast path: rows are staged with s_r = t2 * area_r (t2 slightly below thr / (1 + thr)) for the screen below; a column tile of
+        // ONE class (nearly all tiles of a large class) stages s_r = +inf for rows of another class and needs no class compare per pair
+        const bool one_cls = fast && __ballot(j < n && cj != cj0) == 0;
+        if (fast) ai.x = __float_as_int((one_cls && i < n && ai.y != cj0) || i >= n ? INFINITY : t2 * __int_as_float(ai.x));
         __builtin_amdgcn_wave_barrier();                 // single wave owns rbox[wv]: LDS ops of one wave are in order
         rbox[wv][lane] = bi; raux[wv][lane] = ai;
         __builtin_amdgcn_wave_barrier();
         u64 m = 0;
         if (fast) {
-            for (int g = 0; g < 8; ++g) {                    // 8 rows per byte of the mask word (constant bit positions)
-                unsigned m8 = 0;
+            // Screen (no false negatives): a hit needs inter > thr * union, i.e. inter > thr / (1 + thr) * (area_j + area_r) up to a few
+            // ulp; t2 is that factor reduced by 2^-18, so `inter' >= s_j + s_r` holds for every hit (inter' = inter whenever both
+            // overlaps are positive; one clamp is enough to keep a disjoint pair's product <= 0).  11 (10) VALU instructions per pair;
+            // the exact test below only runs for rows where some lane passes (~1 row in 10 of a dense scene).
+            auto row_bits = [&](auto with_cls) {
+                for (int g = 0; g < 8; ++g) {                // 8 rows per byte of the mask word (constant bit positions)
+                    unsigned m8 = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f32x4 r = rbox[wv][g * 8 + q];
-                    const int2 ra = raux[wv][g * 8 + q];
-                    const float iw = vmax0(vmin(r[2], bj[2]) - vmax(r[0], bj[0]));
-                    const float ih = vmax0(vmin(r[3], bj[3]) - vmax(r[1], bj[1]));
-                    const float inter = iw * ih;
-                    const float uni = (aj + __int_as_float(ra.x)) - inter;
-                    // screen: fma(-thr, u, inter) < 0 (one rounding: the sign is exact) => inter / u < thr => no hit; the
-                    // exact test only runs for rows where some lane passes the screen (~1 row in 10 of a dense scene)
-                    const bool maybe = (ra.y == cj) && !(__builtin_fmaf(-thr, uni, inter) < 0.f);
-                    if (__builtin_amdgcn_ballot_w64(maybe)) {
-                        const bool hit = maybe && ((double)inter > mid * (double)uni);
-                        m8 |= hit ? (1u << q) : 0u;
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x4 r = rbox[wv][g * 8 + q];
+                        const int2 ra = raux[wv][g * 8 + q];
+                        const float iwc = vmax0(vmin(r[2], bj[2]) - vmax(r[0], bj[0]));
+                        const float ihr = vmin(r[3], bj[3]) - vmax(r[1], bj[1]);
+                        bool maybe = iwc * ihr >= sj + __int_as_float(ra.x);
+                        if (with_cls) maybe = maybe && ra.y == cj;
+                        if (__builtin_amdgcn_ballot_w64(maybe)) {
+                            const float inter = iwc * vmax0(ihr);
+                            const float uni = (aj + (r[2] - r[0]) * (r[3] - r[1])) - inter;
+                            const bool hit = maybe && ra.y == cj && ((double)inter > mid * (double)uni);
+                            m8 |= hit ? (1u << q) : 0u;
+                        }
                     }
+                    m |= (u64)m8 << (8 * g);
                 }
-                m |= (u64)m8 << (8 * g);
-            }
+            };
+            if (one_cls) row_bits(std::false_type{}); else row_bits(std::true_type{});
         } else {
             const int cls_j = cj & (TAME_BIT - 1);
 #pragma unroll 4
@@ -911,8 +934,9 @@ extern "C" int yv3_postproc_nms(const float* dets, int B, int N, int num_class, 
         // exact division-free compare (see mask_kernel) for thresholds that are positive normal floats
         const int fast_ok = nms_thr >= 1.17549435e-38f && nms_thr < 1e30f;
         const double mid = fast_ok ? 0.5 * ((double)nms_thr + (double)nextafterf(nms_thr, INFINITY)) : 0.0;
+        const float t2 = fast_ok ? (float)((double)nms_thr / (1.0 + (double)nms_thr) * (1.0 - 1.0 / 262144.0)) : 0.f;   // screen factor
         hipLaunchKernelGGL(mask_kernel, dim3((unsigned)mb, B), dim3(256), mask_lds, s,
-                           cand_counts, max_cand, ws, max_n, num_class, nms_thr, mid, fast_ok);
+                           cand_counts, max_cand, ws, max_n, num_class, nms_thr, mid, t2, fast_ok);
         YV3_CHECK_LAUNCH();
         // one workgroup per (image, class) segment for small batches; a large batch (sparse scenes in practice: most segments are
         // empty) loops ~2048 / B workgroups per image over the classes
