@@ -309,6 +309,67 @@ def attach_traffic(roof, dtype, size, B, n_desc):
                                 "gfx950 calibration in MI355X_MICROARCH.md" % n_desc)
 
 
+def sum_counter(csv_path, family):
+    """(sum of Counter_Value, number of dispatches) over the kernels of `family` in a rocprofv3 counter_collection.csv."""
+    import csv
+    per = {}
+    with open(csv_path) as f:
+        for r in csv.DictReader(f):
+            if family in r["Kernel_Name"]:
+                per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return sum(per.values()), len(per)
+
+
+def live_traffic(roof, args, B, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel family, measured for THIS binary on THIS box: two rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over a 3-step one-lane run of the same
+    workload in child processes (counters cannot be sampled from inside this process).  traffic = (2*FETCH + WRITE) * 1024 /
+    launches: KiB units, FETCH_SIZE doubled per the guide's gfx950 calibration.  Returns False (and leaves `roof` alone) when
+    rocprofv3 is missing or a pass fails; the caller then attaches the committed summary instead."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        roof["traffic_live_error"] = "rocprofv3 not found"
+        return False
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        roof["traffic_live_error"] = "this process is itself being profiled"
+        return False
+    fam = KERNEL_NAME[args.dtype].split("<")[0]
+    sums = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="yv3_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+               os.path.abspath(__file__), "--lanes", "1", "--no-extras", "--no-cpu-baseline", "--no-live-traffic", "--steps", "3",
+               "--warmup", "1", "--batch", str(B), "--size", str(args.size), "--dtype", args.dtype, "--weights", args.weights,
+               "--conf", str(args.conf), "--nms", str(args.nms)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            sums[ctr] = sum_counter(hits[0], fam)
+        except Exception as e:                                     # noqa: BLE001 -- any failure means "use the committed summary"
+            roof["traffic_live_error"] = "%s pass: %s" % (ctr, type(e).__name__)
+            return False
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    (f, nf), (w, nw) = sums["FETCH_SIZE"], sums["WRITE_SIZE"]
+    if nf == 0 or nf != nw:
+        roof["traffic_live_error"] = "dispatch counts differ (%d / %d)" % (nf, nw)
+        return False
+    roof["traffic"] = round((2 * f + w) * 1024 / nf)
+    roof["traffic_source"] = "measured in this run"
+    roof["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / %d profiled launches of %s: two rocprofv3 --pmc "
+                            "passes (one counter each) over 3 one-lane steps of this workload in child processes, %.0f s; FETCH_SIZE "
+                            "doubled per the gfx950 calibration in MI355X_MICROARCH.md; algorithmic bytes per launch: flop-independent, "
+                            "see DESIGN.md section 3" % (nf, fam, time.time() - t0))
+    return True
+
+
 def dry_run(args, rank, world):
     """Launcher / rendezvous / collective / JSON-line rehearsal on CPU tensors: every rank builds a synthetic payload
     with the PRODUCT's pack function, runs the product's single all-gather K times (barrier + max-over-ranks timing as
@@ -364,6 +425,8 @@ def main():
                     "2 when it measures a gain on this GPU, else 1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra modes / configs measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic "
+                    "(~1 min, N=1 only); attach the committed summary of such passes instead")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collective rehearsal on CPU tensors (no GPU needed)")
     ap.add_argument("--weights", default="sw1", choices=["sw1", "dense", "eval"],
                     help="sw1: ~50-150 candidates/img; dense: ~1e4 rows/img pass conf (BASELINE configs[4]); eval: SW-eval")
@@ -451,7 +514,8 @@ def main():
                                                 "mean what they say; the timed step above runs %d concurrent lanes" % (head1["value"], head1["ms_per_step"], lanes_used))
             out["roofline"]["two_lanes_section"] = {k: head["roofline"][k] for k in ("kernel", "achieved", "frac", "launches")}
             out["lanes_calibration_ms"] = getattr(main_w.det, "lane_calibration", None)
-        attach_traffic(out["roofline"], args.dtype, args.size, B, n_desc)
+        if args.no_live_traffic or world > 1 or not live_traffic(out["roofline"], args, B):
+            attach_traffic(out["roofline"], args.dtype, args.size, B, n_desc)
         if args.dtype in ("f32x3", "f32h2"):
             nm = {"f32x3": 6, "f32h2": 3}[args.dtype]
             ach = out["roofline"]["achieved"]

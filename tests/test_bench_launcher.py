@@ -42,3 +42,19 @@ def test_too_few_gpus_is_an_error_not_a_one_rank_run():
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_live_traffic_counter_parsing(tmp_path):
+    """bench.live_traffic sums a rocprofv3 counter_collection.csv per kernel family: per dispatch (a counter can appear once per
+    XCD / shader engine for the same dispatch), only the family's kernels."""
+    import bench
+    p = tmp_path / "t_counter_collection.csv"
+    p.write_text('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",'
+                 '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value"\n'
+                 '1,1,0,1,9,9,512,3,"void (anonymous namespace)::conv_planes_kernel<2, 256, 128>(ConvParamsP)",512,0,0,128,0,96,"FETCH_SIZE",100.5\n'
+                 '1,1,0,1,9,9,512,3,"void (anonymous namespace)::conv_planes_kernel<2, 256, 128>(ConvParamsP)",512,0,0,128,0,96,"FETCH_SIZE",20\n'
+                 '2,2,0,1,9,9,512,4,"(anonymous namespace)::mask_kernel(int const*)",256,0,0,34,0,60,"FETCH_SIZE",7\n'
+                 '3,3,0,1,9,9,512,3,"void (anonymous namespace)::conv_planes_kernel<2, 128, 128>(ConvParamsP)",512,0,0,128,0,96,"FETCH_SIZE",30\n')
+    total, n = bench.sum_counter(str(p), "conv_planes_kernel")
+    assert n == 2 and abs(total - 150.5) < 1e-9
+    assert bench.sum_counter(str(p), "conv_igemm_f32_kernel") == (0, 0)

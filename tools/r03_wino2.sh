@@ -8,7 +8,7 @@ BB=32 timeout 600 python tools/wino_ab.py c26 c13 >> $O/r03_wino_ab2.log 2>&1; t
 out=$O/r03_wino_net_ab2.log; : > $out
 for pass in 1 2; do
 for v in "BASE=1" "YV3_WINO=1 YV3_WINO_TILE_SCHEDULE=1" "YV3_WINO=1"; do
-  line=$(env $v python bench.py --steps 40 --warmup 8 --no-extras --no-cpu-baseline 2>/dev/null | tail -1)
+  line=$(env $v python bench.py --steps 40 --warmup 8 --no-extras --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1)
   echo "$v pass$pass $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], "img/s", d["ms_per_step"], "ms lanes", d["lanes"], "one-lane", d["roofline"].get("measured_with","")[:40])')" >> $out
 done; done
 cat $out

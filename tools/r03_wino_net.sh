@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out; mkdir -p $O; out=$O/r03_wino_net_ab.log; : > $out
 for pass in 1 2; do
 for v in "BASE=1" "YV3_WINO=1 YV3_WINO_MIN_CIN=512" "YV3_WINO=1 YV3_WINO_MIN_CIN=256"; do
-  line=$(env $v python bench.py --steps 40 --warmup 8 --no-extras --no-cpu-baseline 2>/dev/null | tail -1)
+  line=$(env $v python bench.py --steps 40 --warmup 8 --no-extras --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1)
   echo "$v pass$pass $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], "img/s", d["ms_per_step"], "ms lanes", d["lanes"], "one-lane", d["roofline"].get("measured_with","")[:40])')" >> $out
 done; done
 cat $out

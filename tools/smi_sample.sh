@@ -1,7 +1,7 @@
 #!/bin/bash
 # Power / clock samples (rocm-smi) while the headline bench loops: evidence for "the dominant kernel is power-limited".
 O=gpurun_out/smi_sample.txt; : > $O
-python bench.py --no-extras --no-cpu-baseline --steps 5000 --warmup 5 > gpurun_out/smi_bench.json 2>/dev/null &
+python bench.py --no-extras --no-cpu-baseline --no-live-traffic --steps 5000 --warmup 5 > gpurun_out/smi_bench.json 2>/dev/null &
 BP=$!
 n=0
 for i in $(seq 1 120); do

@@ -3,7 +3,7 @@
 # Tries every readout this image offers; whatever works is logged verbatim.
 export TMPDIR=/tmp
 O=gpurun_out/r03_throttle_status_during_bench.txt; : > $O
-python bench.py --no-extras --no-cpu-baseline --steps 4000 --warmup 5 > gpurun_out/r03_throttle_bench.json 2>/dev/null &
+python bench.py --no-extras --no-cpu-baseline --no-live-traffic --steps 4000 --warmup 5 > gpurun_out/r03_throttle_bench.json 2>/dev/null &
 BP=$!
 sleep 25
 for i in 1 2 3; do
