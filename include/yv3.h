@@ -198,6 +198,8 @@ typedef struct yv3_conv_desc {
 #define YV3_OPT_K3S1        2u    /* 3x3 stride-1 plane convs: the kw-tap-reuse kernel (conv_planes_k3s1.hip)          */
 #define YV3_OPT_WINO_EVEN   4u    /* Winograd stage: even (stream-K over transform positions) schedule instead of one tile per workgroup */
 #define YV3_OPT_WINO_ALWAYS 8u    /* Winograd stage whenever w_wino is set, whatever the tile count                                     */
+#define YV3_OPT_TWO_LANES   16u   /* the caller runs an equal launch sequence on a second stream at the same time (two lanes of one batch):
+                                     the Winograd rule's lower bound counts both lanes' tiles (0.27 instead of 0.55 rounds per launch)  */
 #define YV3_OPT_TILE_SHIFT  8     /* bits 8..15: force a tile configuration of the fp16-plane kernels (0 = automatic):
                                      1 = 256x128 / 8 waves, 2 = 128x128 / 8 waves, 3 = 128x128 / 4 waves, two workgroups per CU */
 

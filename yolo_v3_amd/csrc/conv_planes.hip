@@ -798,7 +798,14 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // 104 tiles (@13x13 bs=32, @19x19 bs=16) x0.78...0.80, and the 128-channel 52x52 layers x0.93 (input transform HBM-bound)
         const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (npad / 128);
         const long long ncu = yv3_num_cu();
-        if ((d->options & YV3_OPT_WINO_ALWAYS) || (tiles * 100 >= 55 * ncu && tiles * 100 <= 105 * ncu)) return launch_wino(d, p, s);
+        // ... and under two concurrent lanes (YV3_OPT_TWO_LANES) the other lane's launch fills the rest of the round: the 13x13 layers at
+        // bs=32 per lane (104 tiles each) run x0.78 alone but the two-lane step gains 2 % with them (profiles/r03y_wino_lower_bound_two_lanes_ab.txt)
+#ifdef YV3_AB_NO_TWO_LANES_RULE
+        const long long lo_pct = 55;
+#else
+        const long long lo_pct = (d->options & YV3_OPT_TWO_LANES) ? 27 : 55;
+#endif
+        if ((d->options & YV3_OPT_WINO_ALWAYS) || (tiles * 100 >= lo_pct * ncu && tiles * 100 <= 105 * ncu)) return launch_wino(d, p, s);
     }
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \

@@ -202,11 +202,13 @@ def batch_split(B, ho, wo, cout_pad, ncu):
 
 
 def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None,
-              batch=None, wino_ws=None):
+              batch=None, wino_ws=None, two_lanes=False):
     """`batch` = (b0, nb): the descriptor covers images b0 .. b0+nb-1 of the [NP][B,...] plane tensors (plane dtypes only)."""
     sp = pc.spec
     d = ConvDesc()
     d.options, d.big_tile_min = tuning_options()
+    if two_lanes:
+        d.options |= _ffi.OPT_TWO_LANES
     for i, v in enumerate((os.environ.get("YV3_TUNE", "") or "0").split(",")[:4]):
         d.tune[i] = int(v or 0)
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
@@ -256,7 +258,9 @@ class Plan:
             raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
         return 3 * sum((H // s) * (W // s) for s in (32, 16, 8)), 5 + engine.num_class
 
-    def __init__(self, engine, B, H, W, flags=None):
+    def __init__(self, engine, B, H, W, flags=None, two_lanes=False):
+        """two_lanes: this plan is one of two equal lanes that run concurrently (`Detector`): tells the library's per-launch
+        kernel choice that the chip is shared (yv3.h YV3_OPT_TWO_LANES)."""
         if H % 32 or W % 32:
             raise _ffi.Yv3Error("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
         self.B, self.H, self.W = B, H, W
@@ -315,7 +319,7 @@ class Plan:
                 split = batch_split(B, ho, wo, pc.cout_pad, ncu)
             for part in ([None] if split is None else [(0, split[0]), (split[0], split[1])]):
                 descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace, batch=part,
-                                       wino_ws=self.wino_ws))
+                                       wino_ws=self.wino_ws, two_lanes=two_lanes))
                 self.desc_spec.append(i)
             if y is not None:
                 self.layer_out[pc.spec.name] = y
