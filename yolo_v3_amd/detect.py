@@ -68,7 +68,9 @@ class Detector:
             if auto2:
                 self._choose_lanes()
             else:
-                self._build_plans(2 if (lanes or 1) >= 2 else 1)
+                self._build_plans(2 if (lanes or 1) >= 2 else 1, self.engine.lane_choices.get("stream_pair"))
+                if self.lanes == 2 and "stream_pair" not in self.engine.lane_choices:
+                    self._pick_stream_pair()              # (a requested second lane must not land on the first one's hardware queue)
         self._graph = None
         self._static_in = None
         self._want_graph = graph
@@ -151,6 +153,28 @@ class Detector:
             lanes = _min_over_group(lanes, self._group, self.device)
         self._build_plans(lanes, streams if lanes > 1 else None)
 
+    def _pick_stream_pair(self):
+        """Two-lane plans are built: time three candidate stream pairs over a few steps each and keep the fastest (a pair that shares
+        a hardware queue serialises: 6.0 instead of 4.2 ms at bs=16, profiles/r03y_lanes_loop_probe.txt); remembered on the engine."""
+        x = torch.rand(self.shape, device=self.device, dtype=torch.float32, generator=torch.Generator(device=self.device).manual_seed(1234))
+        noop = lambda name: None
+        best = None
+        for pair in [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]:
+            self.lane_streams = pair
+            for _ in range(2):
+                self._run_lanes(x, noop)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                self._run_lanes(x, noop)
+            torch.cuda.synchronize(self.device)
+            t = time.perf_counter() - t0
+            if best is None or t < best[0]:
+                best = (t, pair)
+        self.lane_streams = best[1]
+        self.lane_plans[0].flags.zero_()
+        self.engine.lane_choices["stream_pair"] = best[1]
+
     def _calibrate_lanes(self):
         B, _, H, W = self.shape
         # image-like values, not zeros: the conv kernels' speed is data-dependent on this power-limited chip (zero operands run
@@ -194,14 +218,18 @@ class Detector:
                     return (time.perf_counter() - t0) / n
 
         # 1. the stream pair: short runs are enough to tell a pair that shares a hardware queue (it serialises) from one that does not
-        best = None
-        self._build_plans(2)
-        for pair in [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]:
-            self.lane_streams = pair
-            t = timed()
-            if best is None or t < best[0]:
-                best = (t, pair)
-        self.lane_streams = best[1]
+        known = self.engine.lane_choices.get("stream_pair")
+        self._build_plans(2, known)
+        if known is None:
+            best = None
+            for pair in [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]:
+                self.lane_streams = pair
+                t = timed()
+                if best is None or t < best[0]:
+                    best = (t, pair)
+            known = self.engine.lane_choices["stream_pair"] = best[1]
+        self.lane_streams = known
+        best = (None, known)
         two_state = snapshot()
         had_plan = (B, H, W) in self.engine._plans
         self._build_plans(1)
