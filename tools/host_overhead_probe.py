@@ -21,3 +21,21 @@ for B in (1, 8, 32):
     for _ in range(n): d(x)
     t_sync = (time.perf_counter() - t0) / n
     print("B=%-2d lanes=%d: enqueue %.3f ms/call (host only), async throughput %.3f ms/call, synchronous call %.3f ms" % (B, d.lanes, t_enq * 1e3, t_async * 1e3, t_sync * 1e3)); sys.stdout.flush()
+
+# enqueue cost without back-pressure from a full command queue: one step at a time, the GPU idle before each
+for B in (1, 16, 64):
+    x = torch.from_numpy(synth.images(B, 416, 5)).cuda()
+    for lanes in (1, 2):
+        if B == 1 and lanes == 2:
+            continue
+        d = Detector(net, B, 416, 416, lanes=lanes)
+        for _ in range(5): d(x)
+        ts = []
+        for _ in range(30):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d.run_device(x)
+            ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        ts.sort()
+        print("B=%-2d lanes=%d: enqueue of ONE step into an idle queue: median %.3f ms, min %.3f ms" % (B, lanes, ts[len(ts) // 2] * 1e3, ts[0] * 1e3)); sys.stdout.flush()
