@@ -183,8 +183,9 @@ typedef struct yv3_conv_desc {
        x 4 of the input scaling folded in.  Results differ from the direct kernel by fp32 round-off only (per-layer error
        ~2x the direct scheme's, tools/winograd_numerics.py).  wino_ws: scratch of yv3_wino_workspace_bytes(B,H,W,cin) bytes,
        ZERO-FILLED once by the caller and then left alone (its tail holds the hand-over flags of the even schedule);
-       launches that may overlap must not share it.  The library takes this path when the layer's 128x128 Winograd tiles fill
-       0.55 ... 1.05 rounds of the chip's CUs (measured crossovers; YV3_OPT_WINO_ALWAYS: whenever w_wino is set) and the direct
+       launches that may overlap must not share it.  The library takes this path by the layer's count of 128x128 Winograd tiles
+       (r = tiles / CUs: r >= 0.62 up to one round, r / ceil(r) >= 0.75 beyond -- measured crossovers; r >= 0.27 with
+       YV3_OPT_TWO_LANES; YV3_OPT_WINO_ALWAYS: whenever w_wino is set) and the direct
        kernel otherwise -- the choice depends on B, so the same image may be computed by either form at different batch sizes
        (both within fp32 round-off of the exact result, not bit-identical to each other).  YV3_OPT_WINO_EVEN: stream-K schedule
        over transform positions (one persistent workgroup per CU; a split tile is summed head + tail). */

@@ -798,14 +798,21 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // 104 tiles (@13x13 bs=32, @19x19 bs=16) x0.78...0.80, and the 128-channel 52x52 layers x0.93 (input transform HBM-bound)
         const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (npad / 128);
         const long long ncu = yv3_num_cu();
-        // ... and under two concurrent lanes (YV3_OPT_TWO_LANES) the other lane's launch fills the rest of the round: the 13x13 layers at
-        // bs=32 per lane (104 tiles each) run x0.78 alone but the two-lane step gains 2 % with them (profiles/r03y_wino_lower_bound_two_lanes_ab.txt)
-#ifdef YV3_AB_NO_TWO_LANES_RULE
-        const long long lo_pct = 55;
-#else
-        const long long lo_pct = (d->options & YV3_OPT_TWO_LANES) ? 27 : 55;
+        // Round 3, later (tools/wino_ab.py over bs = 48 ... 256, profiles/r03x_wino_rounds_map.log): what decides is how full the LAST
+        // round of tiles is.  r = tiles / CUs: 0.59 x0.89, 0.78 x1.38, 0.97 x1.27, 1.00 x1.15 | 1.16 x0.85, 1.33 x0.94, 1.53 x1.06, 1.66 x1.16,
+        // 1.94 x1.29, 2.31 x1.01, 2.64 x1.14, 3.06 x1.07, 3.97 x1.13, 5.28 x1.09.  Rule for a launch that has the chip to itself:
+        // up to one round r >= 0.62; beyond, r / ceil(r) >= 0.75.  Under two concurrent lanes (YV3_OPT_TWO_LANES) the other lane's
+        // launch fills the idle part of a round: r >= 0.27 (the 13x13 layers at 32 images per lane, 104 tiles, run x0.78 alone but the
+        // two-lane step gains 2.6-3.8 % with them; at 64 / 128 images per lane the 1.33-round 26x26 layers gain too: bs=128 +2.9 %, bs=256
+        // +5.5 %, profiles/r03y_wino_two_lanes_rule_ab.txt, r03x_wino_big_batch.txt)
+        bool wino;
+        if (d->options & YV3_OPT_WINO_ALWAYS) wino = true;
+#ifndef YV3_AB_NO_TWO_LANES_RULE
+        else if (d->options & YV3_OPT_TWO_LANES) wino = tiles * 100 >= 27 * ncu;
 #endif
-        if ((d->options & YV3_OPT_WINO_ALWAYS) || (tiles * 100 >= lo_pct * ncu && tiles * 100 <= 105 * ncu)) return launch_wino(d, p, s);
+        else if (tiles * 100 <= 105 * ncu) wino = tiles * 100 >= 62 * ncu;
+        else wino = tiles * 100 >= 75 * ((tiles + ncu - 1) / ncu) * ncu;
+        if (wino) return launch_wino(d, p, s);
     }
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
