@@ -285,7 +285,8 @@ class Plan:
         if engine.winograd and dt in (F32H2, F32) and not engine.batch_split:      # (batch_split slices the same layers: direct kernels only)
             wsb = _ffi.lib().yv3_wino_workspace_bytes
             # eligible layers read 64 channels at H/4 (F32 only), 128 at H/8, 256 at H/16, 512 at H/32: the shallowest one is the largest
-            need = wsb(B, H // 4, W // 4, 64) if dt == F32 else max(wsb(B, H // 16, W // 16, WINO_MIN_CIN), wsb(B, H // 32, W // 32, 512))
+            lo = WINO_MIN_CIN_F32 if dt == F32 else WINO_MIN_CIN
+            need = max(wsb(B, H // f, W // f, c) for c, f in ((64, 4), (128, 8), (256, 16), (512, 32)) if c >= min(lo, 512))
             self.wino_ws = torch.zeros(need, device=dev, dtype=torch.uint8)       # (zero-filled: hand-over flags of the even schedule)
 
         def buf(h, w, c, dtype=dt):
