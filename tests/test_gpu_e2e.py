@@ -9,7 +9,7 @@ import torch
 
 from oracle import oracle_cpu as oc
 from yolo_v3_amd import synth, detect, postprocessing, Detector, _ffi
-from tests.helpers import TOL, assert_close_rel, match_boxes, check_result_convention, load_sw1_net, detector_dets
+from tests.helpers import TOL, assert_close_rel, match_boxes, check_result_convention, load_sw1_net, detector_dets, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -200,6 +200,28 @@ def test_full_size_properties(net, sw1_stream):
         assert torch.equal(res_d[i], ref_d[i])                # direct kernels: independent of batch size / position, bit for bit
     for i in range(8, 32):
         assert torch.equal(res_d[i], res_d[i % 8])
+
+
+@pytest.mark.parametrize("B,lanes", [(128, 1), (96, 2)])
+def test_large_batches_take_the_winograd_form_and_keep_the_boxes(net, sw1_stream, B, lanes):
+    """Above 64 images per GPU the per-launch rule selects the Winograd form by the fill of the LAST round of tiles (one lane,
+    bs=128: 2.64 and 1.53 rounds) or because the chip is shared (two lanes, 48 images each: YV3_OPT_TWO_LANES): the boxes equal
+    those of the direct kernels (``net.winograd = False``) within the 1e-4 parity tolerance, image for image, and the
+    detections tensors agree within the same tolerance."""
+    base = synth.images(16, 416, 123)
+    x = torch.from_numpy(base[[i % 16 for i in range(B)]]).cuda()
+    det = Detector(net, B, 416, 416, lanes=lanes)
+    res = det(x)
+    dets_w = det.dets.clone()
+    direct = load_sw1_net(sw1_stream).cuda()
+    direct.winograd, direct.stream_k = False, False
+    ddet = Detector(direct, B, 416, 416, lanes=lanes)
+    res_d = ddet(x)
+    assert len(res) == len(res_d) == B
+    assert not torch.equal(dets_w, ddet.dets), "the Winograd form was expected to run for some layers at this batch size"
+    assert_close_rel(dets_w, ddet.dets, TOL, "Winograd vs direct detections")
+    for a, b in zip(res[:32], res_d[:32]):
+        match_boxes(a, b)
 
 
 def test_weights_change_is_picked_up(net, sw1_stream):
