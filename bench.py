@@ -320,7 +320,7 @@ def sum_counter(csv_path, family):
     return sum(per.values()), len(per)
 
 
-def live_traffic(roof, args, B, timeout_s=150):
+def live_traffic(roof, args, B, timeout_s=150, dtype=None, size=None, weights=None, conf=None, nms=None):
     """HBM bytes per launch of the dominant kernel family, measured for THIS binary on THIS box: two rocprofv3 --pmc passes
     (FETCH_SIZE, WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over a 3-step one-lane run of the same
     workload in child processes (counters cannot be sampled from inside this process).  traffic = (2*FETCH + WRITE) * 1024 /
@@ -336,7 +336,9 @@ def live_traffic(roof, args, B, timeout_s=150):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         roof["traffic_live_error"] = "this process is itself being profiled"
         return False
-    fam = KERNEL_NAME[args.dtype].split("<")[0]
+    dtype, size, weights = dtype or args.dtype, size or args.size, weights or args.weights
+    conf, nms = args.conf if conf is None else conf, args.nms if nms is None else nms
+    fam = KERNEL_NAME[dtype].split("<")[0]
     sums = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -346,8 +348,8 @@ def live_traffic(roof, args, B, timeout_s=150):
         d = tempfile.mkdtemp(prefix="yv3_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
                os.path.abspath(__file__), "--lanes", "1", "--no-extras", "--no-cpu-baseline", "--no-live-traffic", "--steps", "3",
-               "--warmup", "1", "--batch", str(B), "--size", str(args.size), "--dtype", args.dtype, "--weights", args.weights,
-               "--conf", str(args.conf), "--nms", str(args.nms)]
+               "--warmup", "1", "--batch", str(B), "--size", str(size), "--dtype", dtype, "--weights", weights,
+               "--conf", str(conf), "--nms", str(nms)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -554,7 +556,8 @@ def main():
             w = Workload(net, x, mode, args.conf, args.nms)
             out["modes"][mode] = w.summary(w.run(sub_steps, sub_warm), sub_steps)
             w.finish()
-            attach_traffic(out["modes"][mode]["roofline"], mode, args.size, B, out["modes"][mode]["roofline"]["launches"])
+            if args.no_live_traffic or world > 1 or not live_traffic(out["modes"][mode]["roofline"], args, B, dtype=mode):
+                attach_traffic(out["modes"][mode]["roofline"], mode, args.size, B, out["modes"][mode]["roofline"]["launches"])
             if mode == "bf16":
                 out["modes"][mode]["note"] = "reduced precision (bf16 conv operands, fp32 accumulate / epilogue / decode): outside the 1e-4 parity bar"
             del w
@@ -566,7 +569,11 @@ def main():
             s = w.summary(w.run(sub_steps, sub_warm), sub_steps)
             s["workload"] = label
             s["candidates_per_img_first4"], s["kept_per_img_first4"] = w.finish()
-            attach_traffic(s["roofline"], mode, x_.shape[2], x_.shape[0], s["roofline"]["launches"])
+            wname = {"1": "sw1", "2": "sw1", "4": "dense"}.get(key)
+            live = wname is not None and not args.no_live_traffic and world == 1 and live_traffic(
+                s["roofline"], args, x_.shape[0], dtype=mode, size=x_.shape[2], weights=wname, conf=conf, nms=nms)
+            if not live:
+                attach_traffic(s["roofline"], mode, x_.shape[2], x_.shape[0], s["roofline"]["launches"])
             out["configs"][key] = s
 
         sub("1", "416x416 bs=32 SW-1 fp32-class (f32h2) conf=0.5 nms=0.4", net, scenes(32, 416, 1, dev), "f32h2", 0.5, 0.4)
