@@ -10,7 +10,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                                                    # noqa: E402
-from yolo_v3_amd import synth                                   # noqa: E402
 from yolo_v3_amd.utils import PostProcessor                     # noqa: E402
 from tools.postproc_bench import CASES                          # noqa: E402
 

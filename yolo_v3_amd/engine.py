@@ -14,7 +14,6 @@ tensors.  Here the whole network is a static plan:
   row order equals the reference's ``torch.cat((det1, det2, det3), 1)``.
 """
 import ctypes
-import math
 import os
 
 import torch
