@@ -320,7 +320,10 @@ def sum_counter(csv_path, family):
     return sum(per.values()), len(per)
 
 
-def live_traffic(roof, args, B, timeout_s=150, dtype=None, size=None, weights=None, conf=None, nms=None):
+LIVE_TRAFFIC = {"ok": True}          # one failed pass (missing tool, time-out, crash) switches the live measurement off for the rest of the run
+
+
+def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=None, conf=None, nms=None):
     """HBM bytes per launch of the dominant kernel family, measured for THIS binary on THIS box: two rocprofv3 --pmc passes
     (FETCH_SIZE, WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over a 3-step one-lane run of the same
     workload in child processes (counters cannot be sampled from inside this process).  traffic = (2*FETCH + WRITE) * 1024 /
@@ -329,9 +332,13 @@ def live_traffic(roof, args, B, timeout_s=150, dtype=None, size=None, weights=No
     import shutil
     import subprocess
     import tempfile
+    if not LIVE_TRAFFIC["ok"]:
+        roof["traffic_live_error"] = "switched off after an earlier failure in this run"
+        return False
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         roof["traffic_live_error"] = "rocprofv3 not found"
+        LIVE_TRAFFIC["ok"] = False
         return False
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         roof["traffic_live_error"] = "this process is itself being profiled"
@@ -356,6 +363,7 @@ def live_traffic(roof, args, B, timeout_s=150, dtype=None, size=None, weights=No
             sums[ctr] = sum_counter(hits[0], fam)
         except Exception as e:                                     # noqa: BLE001 -- any failure means "use the committed summary"
             roof["traffic_live_error"] = "%s pass: %s" % (ctr, type(e).__name__)
+            LIVE_TRAFFIC["ok"] = False
             return False
         finally:
             shutil.rmtree(d, ignore_errors=True)
