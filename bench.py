@@ -358,7 +358,17 @@ def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=Non
                "--warmup", "1", "--batch", str(B), "--size", str(size), "--dtype", dtype, "--weights", weights,
                "--conf", str(conf), "--nms", str(nms)]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            # own session: on a time-out the whole group (rocprofv3 AND the python it started) is killed, nothing keeps the GPU busy
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                raise
+            if proc.returncode != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd[0])
             hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             sums[ctr] = sum_counter(hits[0], fam)
         except Exception as e:                                     # noqa: BLE001 -- any failure means "use the committed summary"
