@@ -271,6 +271,33 @@ def test_nms_long_single_class_segment():
     assert len(res[0]) > 300
 
 
+@pytest.mark.parametrize("C", [200, 300])
+def test_postprocessing_many_classes(C):
+    """Class counts beyond the 80 of COCO take other code paths: above 183 classes the filter's LDS staging is off, above 256 the
+    sort runs without the per-class sub-partitions (one partition per class).  Clustered boxes, one class with ~1000
+    candidates (sub-partitioned when C = 200), bit-exact vs the oracle in NMS, eval and raw mode."""
+    B, N = 2, 2600
+    u = synth.uniform01(700 + C, 1, B * N * 8).reshape(B, N, 8)
+    d = np.zeros((B, N, 5 + C), dtype=np.float32)
+    d[..., 0] = 60 + u[..., 0] * 300
+    d[..., 1] = 60 + u[..., 1] * 300
+    d[..., 2] = 20 + u[..., 2] * 60
+    d[..., 3] = 20 + u[..., 3] * 60
+    d[..., 4] = np.where(u[..., 4] < 0.6, 0.55 + 0.44 * u[..., 5], 0.2 * u[..., 5])
+    d[..., 5:] = synth.uniform01(701 + C, 2, B * N * C).reshape(B, N, C) * 0.5
+    cls = np.where(u[..., 6] < 0.7, C - 3, (u[..., 7] * C).astype(np.int64))
+    bi, ri = np.meshgrid(np.arange(B), np.arange(N), indexing="ij")
+    d[bi, ri, 5 + cls] = 0.75 + 0.24 * u[..., 7]
+    dt = torch.from_numpy(d)
+    for thr, is_eval, use_nms in ((0.5, False, True), (0.45, True, True), (0.5, False, False)):
+        ref = oc.postprocess(dt, C, thr, 0.4, is_eval, use_nms)
+        res = postprocessing(dt.cuda(), C, thr, 0.4, is_eval, use_nms)
+        check_result_convention(res, ref)
+        for r, e in zip(res, ref):
+            assert torch.equal(r, e)
+    assert max(len(r) for r in oc.postprocess(dt, C, 0.5, 0.4, False, False)) > 1000
+
+
 # ----------------------------------------------------------------------------- convolutions
 def _rand_cbr(cin, cout, k, s, seed):
     m = conv_bn_relu(cin, cout, k, s)
