@@ -213,6 +213,15 @@ size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin);
 /* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */
 int yv3_conv2d(const yv3_conv_desc* desc, void* stream);
 
+/* Which form would yv3_conv2d run for this descriptor ON THE CURRENT DEVICE (the per-launch rule depends on the CU count)?
+ * YV3_FORM_DIRECT (0): the direct implicit-GEMM kernel (36 multiplications per 2x2 outputs and channel pair for a 3x3 layer);
+ * YV3_FORM_WINOGRAD (1): input transform + 16-position GEMM (16 per 2x2 outputs: 2.25x fewer matrix instructions).
+ * Negative: the YV3_E* code yv3_conv2d would return for it.  Launches nothing; used by tests (assert which plan ran) and by
+ * bench.py (executed vs algorithmic FLOPs). */
+#define YV3_FORM_DIRECT   0
+#define YV3_FORM_WINOGRAD 1
+int yv3_conv2d_form(const yv3_conv_desc* desc);
+
 /* Run `n` convolutions back to back on `stream` (one host call for a whole network plan). */
 int yv3_conv2d_sequence(const yv3_conv_desc* descs, int n, void* stream);
 

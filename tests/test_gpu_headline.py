@@ -1,0 +1,176 @@
+"""The plans the benchmark actually times, against the CPU oracle (-m gpu, through the C-ABI).
+
+The kernel FORM of a 3x3 layer (direct implicit GEMM or Winograd F(2x2,3x3)) is chosen per launch from the tile count, the
+lane count and the CU count (csrc/conv_planes.hip: yv3_conv2d_planes_form), so "bs=32 one lane is green" does not imply
+"bs=64 two lanes is green".  This file closes that gap:
+
+  * the headline workload of bench.py (416x416 bs=64, the 64 scenes ``scenes(64, 416, 1000)``, default math mode) through
+    `Detector` with automatic lanes AND with both lane counts forced, all 64 images vs the oracle, with the plan's forms
+    asserted through ``yv3_conv2d_form`` (reference path: test.py:35-36);
+  * the whole network with the Winograd form FORCED on every eligible layer (``net.winograd = "always"``), both
+    Winograd-capable math modes, vs the oracle and the reference's golden boxes;
+  * BASELINE configs[3] at its full size, functionally: 8 ranks (gloo; they time-share the one GPU), global batch 256,
+    ``detect_sharded`` == single-GPU ``detect`` of the same 256 images, bit for bit (utils.py:152: images are independent).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_cpu as oc
+from oracle.boxdelta import boxes_delta
+from yolo_v3_amd import synth, detect, Detector, _ffi, arch
+from tests.helpers import TOL, assert_close_rel, match_boxes, load_sw1_net
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sw1_sd(sw1_stream):
+    return oc.state_dict_from_stream(sw1_stream)[0]
+
+
+@pytest.fixture(scope="module")
+def headline(sw1_sd):
+    """bench.py's headline batch (``scenes(64, 416, 1000)`` at rank 0 = ``synth.images(64, 416, 1000)``) and the oracle's
+    detections + boxes for all 64 images (~6-10 s of CPU)."""
+    x = torch.from_numpy(synth.images(64, 416, 1000))
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref = torch.cat(oc.yolonet_forward(sw1_sd, x), 1)
+    return x, ref, oc.postprocess(ref, 80, 0.5, 0.4)
+
+
+def _form_counts(plan):
+    """{(cin, cout, k, stride, Hout): [launches, of which Winograd]} of one plan's launch sequence."""
+    specs = arch.conv_specs()
+    hw = arch.conv_output_hw(plan.H)
+    out = {}
+    for si, f in plan.forms():
+        sp = specs[si]
+        key = (sp.cin, sp.cout, sp.k, sp.stride, hw[si][0])
+        c = out.setdefault(key, [0, 0])
+        c[0] += 1
+        c[1] += f
+    return out
+
+
+@pytest.mark.parametrize("lanes", [None, 2, 1])
+def test_headline_plan_vs_oracle(sw1_stream, headline, lanes):
+    """bench.py's timed step, as bench.py builds it (`Workload`: ``Detector(net, 64, 416, 416, 0.5, 0.4, lanes=None)``), on
+    bench.py's 64 scenes: every detection value of all 64 images within 1e-4 * max(1,|ref|) of the oracle, final boxes
+    set-wise (class + IOU >= 0.999; random scenes are not margin-selected) with matched boxes within 1e-4 and <= 1 %
+    unmatched.  The plan is asserted, not assumed: with two lanes of 32 images every 256->512 @26x26 and 512->1024 @13x13
+    layer (18 launches per lane) must take the Winograd form; with one lane of 64 the seven 13x13 layers.  lanes=None is
+    the automatic choice the benchmark runs (two lanes wherever the calibration finds a concurrent stream pair)."""
+    x, ref, want = headline
+    net = load_sw1_net(sw1_stream).cuda()
+    det = Detector(net, 64, 416, 416, 0.5, 0.4, lanes=lanes)
+    if lanes is not None:
+        assert det.lanes == lanes
+    with torch.no_grad():
+        res = det(x.cuda())
+    forms = [_form_counts(p) for p in det.lane_plans]
+    c26, c13 = (256, 512, 3, 1, 26), (512, 1024, 3, 1, 13)
+    for fc in forms:
+        assert fc[c26][0] == 11 and fc[c13][0] == 7
+        if det.lanes == 2:
+            assert det.lane_plans[0].B == 32 and fc[c26][1] == 11 and fc[c13][1] == 7, fc
+        else:
+            assert fc[c26][1] == 0 and fc[c13][1] == 7, fc
+        assert sum(v[1] for k, v in fc.items() if k not in (c26, c13)) == 0
+    err = assert_close_rel(det.dets.cpu(), ref, TOL, "headline detections (lanes=%s)" % det.lanes)
+    d = boxes_delta(res, want, 64)
+    print("headline plan lanes=%s -> %d: winograd launches per lane %s; max det err %.3g; boxes %s"
+          % (lanes, det.lanes, [sum(v[1] for v in fc.values()) for fc in forms], err, d))
+    assert d["ref_boxes"] > 600
+    assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["max_abs_err_score"] <= TOL
+    assert d["unmatched_frac"] <= 0.01, d
+    # decisions on IDENTICAL detections (the detector's own) are the oracle's, bit for bit
+    exact = oc.postprocess(det.dets.cpu(), 80, 0.5, 0.4)
+    assert len(res) == len(exact)
+    for a, b in zip(res, exact):
+        assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode,n_wino", [(_ffi.F32H2, 18), (_ffi.F32, 31)])
+def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mode, n_wino):
+    """``net.winograd = "always"`` (YV3_OPT_WINO_ALWAYS on every descriptor): ALL eligible layers -- 18 in the fp16-plane mode
+    (cin >= 256), 31 in the exact-fp32 mode (cin >= 64) -- in the Winograd form at a batch size whose tile counts would
+    otherwise select the direct kernels for most of them; 32 images (BASELINE configs[1]'s batch) vs the oracle, plus the
+    reference's own golden boxes for the dog image."""
+    net = load_sw1_net(sw1_stream).cuda()
+    net.winograd = "always"
+    net.math_mode = mode
+    x = torch.from_numpy(synth.images(32, 416, 1))
+    with torch.no_grad():
+        ref = torch.cat(oc.yolonet_forward(sw1_sd, x), 1)
+        got = net.forward_cat(x.cuda()).cpu()
+    plan = net.engine().plan(32, 416, 416)
+    fc = _form_counts(plan)
+    assert sum(v[1] for v in fc.values()) == n_wino, fc
+    assert all(v[1] in (0, v[0]) for v in fc.values())
+    err = assert_close_rel(got, ref, TOL, "forced-Winograd detections mode %d" % mode)
+    want = oc.postprocess(ref, 80, 0.5, 0.4)
+    res = detect(net, x.cuda(), 80, 0.5, 0.4)
+    d = boxes_delta(res, want, 32)
+    print("forced Winograd mode %d: %d Winograd launches, max det err %.3g; boxes %s" % (mode, n_wino, err, d))
+    assert d["ref_boxes"] > 300 and d["unmatched_frac"] <= 0.01, d
+    assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["max_abs_err_score"] <= TOL
+    # the reference's own output for the dog image (tests/golden/e2e.npz)
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    dog = torch.from_numpy(g["dog_u8"].astype(np.float32) / np.float32(255.0)).permute(2, 0, 1).unsqueeze(0).contiguous().cuda()
+    with torch.no_grad():
+        dets = net.forward_cat(dog)
+    assert sum(f for _, f in net.engine().plan(1, 416, 416).forms()) == n_wino
+    e_dog = assert_close_rel(dets[:, g["dog416_rows"]].cpu(), g["dog416_dets_rows"], TOL, "dog image, forced Winograd")
+    fused = detect(net, dog, 80, 0.5, 0.4)
+    assert len(fused) == int(g["dog416_nres"][0])
+    worst = max(match_boxes(f, g["dog416_boxes%d" % i], TOL) for i, f in enumerate(fused))
+    print("forced Winograd mode %d, dog image vs the reference's golden: det err %.3g, box err %.3g" % (mode, e_dog, worst))
+
+
+def test_deterministic_switch_is_bitwise_across_batch_sizes_and_lanes(sw1_stream):
+    """``net.deterministic = True``: ONE switch that restores "same image -> same bits" at every batch size, batch position and
+    lane request (direct one-tile-per-workgroup kernels, no stream-K, a single lane)."""
+    net = load_sw1_net(sw1_stream).cuda()
+    net.deterministic = True
+    x = torch.from_numpy(synth.images(24, 416, 77)).cuda()
+    with torch.no_grad():
+        full = net.forward_cat(x).clone()
+        one = net.forward_cat(x[5:6]).clone()            # B = 1: stream-K would be automatic without the switch
+        part = net.forward_cat(x[16:24]).clone()
+    assert torch.equal(full[5:6], one) and torch.equal(full[16:24], part)
+    det = Detector(net, 24, 416, 416, lanes=2)             # a requested second lane is declined
+    assert det.lanes == 1
+    assert all(f == 0 for _, f in det.plan.forms())
+    res = det(x)
+    res1 = detect(net, x[5:6])
+    assert torch.equal(res[5], res1[0]) if res1 else res[5].numel() == 0
+
+
+def test_config4_full_size_8_ranks_equals_single_gpu():
+    """BASELINE configs[3] ("416x416 bs=256 sharded data-parallel across 8 GPUs, RCCL box gather") at its full size, functionally:
+    tests/dist_config4_worker.py runs as 8 ranks that time-share this box's one GPU (gloo carries the gather: RCCL wants one GPU
+    per rank), each taking its contiguous 32-image shard of the SAME 256 scenes through ``detect_sharded``; rank 0 then runs the
+    single-GPU ``detect`` on all 256 images and compares: same list, same shapes, same bits (``net.deterministic = True`` on both
+    sides -- with the per-launch kernel choice the 32-image and the 256-image plans may differ in the last bits)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["YV3_DIST_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_config4_worker.py")]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("config 4, 8 ranks on one GPU:", out)
+    assert out["world"] == 8 and out["images"] == 256 and out["shard"] == 32 and out["collectives_per_call"] == 1
+    assert out["bitwise_equal_images"] == 256 and out["boxes"] > 2000 and out["default_mode_unmatched_frac"] <= 0.01

@@ -15,7 +15,7 @@ from .darknet import (YoloNet, Darknet, PreDetectionConvGroup, UpsampleGroup, We
                       conv_bn_relu, res_layer)
 from .yololayer import YoloLayer               # noqa: F401
 from .utils import (postprocessing, iou_vectorized, bbox_iou, PostProcessor, letterbox_transforms,    # noqa: F401
-                    letterbox_batch, resize_batch, letterbox_image, load_image)
+                    letterbox_batch, resize_batch, letterbox_image, load_image, clear_postproc_cache)
 from .boundingbox import bbox_cxcywh_to_x1y1x2y2, correct_yolo_boxes, letterbox_reverse, rescale_bbox   # noqa: F401
 from .detect import detect, Detector, predict  # noqa: F401
 from .dist import detect_sharded                # noqa: F401

@@ -3,6 +3,8 @@
 
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s);
 int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s);
+int yv3_conv2d_f32_form(const yv3_conv_desc* d);
+int yv3_conv2d_planes_form(const yv3_conv_desc* d, int np);
 
 extern "C" int yv3_version(void) { return YV3_VERSION; }
 
@@ -44,6 +46,15 @@ extern "C" int yv3_conv2d(const yv3_conv_desc* d, void* stream) {
         if (d->cin % 32) return YV3_ESHAPE;
         return yv3_conv2d_planes(d, d->dtype == YV3_BF16 ? 1 : d->dtype == YV3_F32_F16X2 ? 2 : 3, (hipStream_t)stream);
     }
+    return YV3_EDTYPE;
+}
+
+extern "C" int yv3_conv2d_form(const yv3_conv_desc* d) {
+    const int rc = check_desc(d);
+    if (rc) return rc;
+    if (d->dtype == YV3_F32) return yv3_conv2d_f32_form(d);
+    if (d->dtype == YV3_F32_F16X2) return yv3_conv2d_planes_form(d, 2);
+    if (d->dtype == YV3_F32_BF16X3 || d->dtype == YV3_BF16) return YV3_FORM_DIRECT;
     return YV3_EDTYPE;
 }
 

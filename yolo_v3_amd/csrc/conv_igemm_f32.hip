@@ -386,6 +386,16 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
     return 0;
 }
 
+// Does this fp32 descriptor take the Winograd F(2x2,3x3) form?  (exported through yv3_conv2d_form)
+int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
+    const bool k3 = d->k == 3, dual = d->cin_up > 0;
+    if (!(d->w_wino && d->alpha_wino && k3 && d->stride == 1 && !dual && d->cout % 128 == 0 && d->cout_pad == d->cout)) return 0;
+    // fp32 MFMA runs at the vector rate, so this layer is matrix-bound whatever its shape: Winograd whenever the 128x128 tiles
+    // (a quarter of the direct kernel's rows) still fill a good part of the chip, or YV3_OPT_WINO_ALWAYS
+    const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (d->cout / 128);
+    return ((d->options & YV3_OPT_WINO_ALWAYS) || tiles * 100 >= 40 * yv3_num_cu()) ? 1 : 0;
+}
+
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     ConvParams p;
     p.x = (const float*)d->x; p.x2 = (const float*)d->x2; p.w = (const float*)d->w;
@@ -402,12 +412,7 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     p.cchunks = d->cin / BK;
     p.nk = p.K / BK;
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
-    if (d->w_wino && d->alpha_wino && k3 && d->stride == 1 && !dual && d->cout % 128 == 0 && d->cout_pad == d->cout) {
-        // fp32 MFMA runs at the vector rate, so this layer is matrix-bound whatever its shape: Winograd whenever the 128x128 tiles
-        // (a quarter of the direct kernel's rows) still fill a good part of the chip, or YV3_OPT_WINO_ALWAYS
-        const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (d->cout / 128);
-        if ((d->options & YV3_OPT_WINO_ALWAYS) || tiles * 100 >= 40 * yv3_num_cu()) return launch_wino_f32(d, p, s);
-    }
+    if (yv3_conv2d_f32_form(d) == 1) return launch_wino_f32(d, p, s);
 
     // Tile selection: widest N tile the layer fills; for launches that would leave most of the
     // 256 CUs idle (small batch at 13x13 / 26x26) fall back to 64x64 tiles for 4x the blocks.

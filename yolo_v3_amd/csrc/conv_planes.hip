@@ -28,6 +28,12 @@ namespace {
 #ifndef YV3_PP_GRP
 #define YV3_PP_GRP(wid) ((wid) >> 2)
 #endif
+// YV3_WABL (timing ablations of the Winograd GEMM stage's ping-pong loop, results INVALID; tools/timeline_wino.py):
+//   1 no DMA pieces in the compute segment   2 both k-steps' fragments read in the load segment (no SPLIT)
+//   4 no fold at the end of a position       8 no MFMAs (fragments kept alive)
+#ifndef YV3_WABL
+#define YV3_WABL 0
+#endif
 
 // PP ("ping-pong"): the 8 waves of the workgroup form two groups of four (one wave per SIMD each) that run
 // half a chunk out of phase: while one group issues a chunk's 24 MFMAs from registers, the other reads its
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         const int grp = YV3_PP_GRP(wid);
         // 32x64 wave tiles (128x128 workgroup tile): the compute segment is only 12 MFMAs per k-step, so the second
         // k-step's fragments are fetched under the first k-step's MFMAs; measured +5 % there, -5 % on 64x64 wave tiles
-        constexpr bool SPLIT = MT == 1;
+        constexpr bool SPLIT = MT == 1 && !(WINO && (YV3_WABL & 2));
 #ifdef YV3_TIMELINE
         unsigned long long tl_load = 0, tl_b1 = 0, tl_comp = 0, tl_b2 = 0, tl_pro = 0, tl_epi = 0, tl_t = tl_entry;
         int tl_items = 0, tl_chunks = 0;
@@ -334,16 +340,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                             const int i = u / MT, j = u % MT;
                             const bf16x8v* wf = &frag[ks][i * NP];
                             const bf16x8v* xf = &frag[ks][NT * NP + j * NP];
-                            if constexpr (NP == 2) acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
+                            if constexpr (WINO && (YV3_WABL & 8)) { asm volatile("" :: "v"(wf[t == 0 ? 1 : 0]), "v"(xf[t == 1 ? 1 : 0])); }
+                            else if constexpr (NP == 2) acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
                             else acc[i][j] = PlaneOps<1>::mfma(wf[0], xf[0], acc[i][j]);
                             constexpr int TOT = KS * NMF * NU;                     // one DMA piece after every (TOT / G)-th MFMA
                             const int mi = (ks * NMF + t) * NU + u;
-                            if (more && (mi * G) / TOT != ((mi + 1) * G) / TOT) dma_piece((mi * G) / TOT);
+                            if (more && !(WINO && (YV3_WABL & 1)) && (mi * G) / TOT != ((mi + 1) * G) / TOT) dma_piece((mi * G) / TOT);
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (WINO) {
-                    if (--wleft == 0) {                                            // end of a transform position: Y += (A^T x A^T)[.][xi] * M
+                    if (--wleft == 0 && !(YV3_WABL & 4)) {                         // end of a transform position: Y += (A^T x A^T)[.][xi] * M
                         wleft = p.Cin / PBK;
                         const int xr = wxi >> 2, xc = wxi & 3;
                         ++wxi;
@@ -744,6 +751,34 @@ static int launch_wino(const yv3_conv_desc* d, ConvParamsP p, hipStream_t s) {
 
 extern "C" size_t yv3_conv_workspace_bytes(void) { return (size_t)YV3_SK_MAX_WG * (YV3_SK_PART_BYTES + sizeof(int)); }
 
+// Does this descriptor take the Winograd F(2x2,3x3) form?  (The per-launch rule of the fp16-plane mode; also exported through
+// yv3_conv2d_form so that callers -- tests, bench.py's executed-FLOP accounting -- see the choice the library makes.)
+int yv3_conv2d_planes_form(const yv3_conv_desc* d, int np) {
+    const int npad = d->cout_pad;
+    const bool k3 = d->k == 3, dual = d->cin_up > 0, out_f32 = d->out_dtype == YV3_F32;
+    if (!(d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino && npad % 128 == 0 &&
+          d->x_plane_stride <= 0 && d->y_plane_stride <= 0)) return 0;
+    // Winograd F(2x2,3x3) when its 128x128 tiles (a quarter of the direct kernel's row count) fill 0.55 ... 1.05 rounds of
+    // the chip: same-box A/B against the direct kernel (tools/wino_ab.py): 256->512 @26x26 bs=32 (172 tiles) x1.28,
+    // 512->1024 @13x13 bs=64 (200) x1.36, 256->512 @38x38 bs=16 (184) x1.26; but 340 tiles (1.33 rounds: @26x26 bs=64) x0.96,
+    // 104 tiles (@13x13 bs=32, @19x19 bs=16) x0.78...0.80, and the 128-channel 52x52 layers x0.93 (input transform HBM-bound)
+    const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (npad / 128);
+    const long long ncu = yv3_num_cu();
+    // Round 3, later (tools/wino_ab.py over bs = 48 ... 256, profiles/r03x_wino_rounds_map.log): what decides is how full the LAST
+    // round of tiles is.  r = tiles / CUs: 0.59 x0.89, 0.78 x1.38, 0.97 x1.27, 1.00 x1.15 | 1.16 x0.85, 1.33 x0.94, 1.53 x1.06, 1.66 x1.16,
+    // 1.94 x1.29, 2.31 x1.01, 2.64 x1.14, 3.06 x1.07, 3.97 x1.13, 5.28 x1.09.  Rule for a launch that has the chip to itself:
+    // up to one round r >= 0.62; beyond, r / ceil(r) >= 0.75.  Under two concurrent lanes (YV3_OPT_TWO_LANES) the other lane's
+    // launch fills the idle part of a round: r >= 0.27 (the 13x13 layers at 32 images per lane, 104 tiles, run x0.78 alone but the
+    // two-lane step gains 2.6-3.8 % with them; at 64 / 128 images per lane the 1.33-round 26x26 layers gain too: bs=128 +2.9 %, bs=256
+    // +5.5 %, profiles/r03y_wino_two_lanes_rule_ab.txt, r03x_wino_big_batch.txt)
+    if (d->options & YV3_OPT_WINO_ALWAYS) return 1;
+#ifndef YV3_AB_NO_TWO_LANES_RULE
+    if (d->options & YV3_OPT_TWO_LANES) return tiles * 100 >= 27 * ncu;
+#endif
+    if (tiles * 100 <= 105 * ncu) return tiles * 100 >= 62 * ncu;
+    return tiles * 100 >= 75 * ((tiles + ncu - 1) / ncu) * ncu;
+}
+
 int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     ConvParamsP p;
     p.x = (const u16*)d->x; p.x2 = (const u16*)d->x2; p.w = (const u16*)d->w;
@@ -790,30 +825,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
         if (rc != -100) return rc;
     }
-    if (d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino && npad % 128 == 0 &&
-        d->x_plane_stride <= 0 && d->y_plane_stride <= 0) {
-        // Winograd F(2x2,3x3) when its 128x128 tiles (a quarter of the direct kernel's row count) fill 0.55 ... 1.05 rounds of
-        // the chip: same-box A/B against the direct kernel (tools/wino_ab.py): 256->512 @26x26 bs=32 (172 tiles) x1.28,
-        // 512->1024 @13x13 bs=64 (200) x1.36, 256->512 @38x38 bs=16 (184) x1.26; but 340 tiles (1.33 rounds: @26x26 bs=64) x0.96,
-        // 104 tiles (@13x13 bs=32, @19x19 bs=16) x0.78...0.80, and the 128-channel 52x52 layers x0.93 (input transform HBM-bound)
-        const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (npad / 128);
-        const long long ncu = yv3_num_cu();
-        // Round 3, later (tools/wino_ab.py over bs = 48 ... 256, profiles/r03x_wino_rounds_map.log): what decides is how full the LAST
-        // round of tiles is.  r = tiles / CUs: 0.59 x0.89, 0.78 x1.38, 0.97 x1.27, 1.00 x1.15 | 1.16 x0.85, 1.33 x0.94, 1.53 x1.06, 1.66 x1.16,
-        // 1.94 x1.29, 2.31 x1.01, 2.64 x1.14, 3.06 x1.07, 3.97 x1.13, 5.28 x1.09.  Rule for a launch that has the chip to itself:
-        // up to one round r >= 0.62; beyond, r / ceil(r) >= 0.75.  Under two concurrent lanes (YV3_OPT_TWO_LANES) the other lane's
-        // launch fills the idle part of a round: r >= 0.27 (the 13x13 layers at 32 images per lane, 104 tiles, run x0.78 alone but the
-        // two-lane step gains 2.6-3.8 % with them; at 64 / 128 images per lane the 1.33-round 26x26 layers gain too: bs=128 +2.9 %, bs=256
-        // +5.5 %, profiles/r03y_wino_two_lanes_rule_ab.txt, r03x_wino_big_batch.txt)
-        bool wino;
-        if (d->options & YV3_OPT_WINO_ALWAYS) wino = true;
-#ifndef YV3_AB_NO_TWO_LANES_RULE
-        else if (d->options & YV3_OPT_TWO_LANES) wino = tiles * 100 >= 27 * ncu;
-#endif
-        else if (tiles * 100 <= 105 * ncu) wino = tiles * 100 >= 62 * ncu;
-        else wino = tiles * 100 >= 75 * ((tiles + ncu - 1) / ncu) * ncu;
-        if (wino) return launch_wino(d, p, s);
-    }
+    if (yv3_conv2d_planes_form(d, np) == 1) return launch_wino(d, p, s);
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
                                          np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, use_pp, s) : \

@@ -291,6 +291,7 @@ class YoloNet(nn.Module):
         state = self.__dict__.copy()
         state["_engines"] = {}
         state.pop("_detectors", None)
+        state.pop("_sharded_detectors", None)
         return state
 
     def __deepcopy__(self, memo):

@@ -51,6 +51,8 @@ class Detector:
         if lanes is None:
             import os
             lanes = getattr(net, "lanes", None) or (int(os.environ["YV3_LANES"]) if os.environ.get("YV3_LANES") else None)
+        if self.engine.deterministic:
+            lanes = 1                    # net.deterministic: one schedule whatever the batch (engine.Engine.__init__)
         self._lanes_req = lanes
         with torch.cuda.device(self.device):
             B = batch
@@ -347,8 +349,12 @@ def _detector_cache(net):
 DETECTOR_CACHE_MAX = 3
 
 
-def cached_detector(net, key, build):
-    cache = _detector_cache(net)
+def cached_detector(net, key, build, sharded=False):
+    """`sharded`: detectors of `detect_sharded` live in their OWN least-recently-used cache.  Building one contains a
+    collective (the MIN-reduction of the lane count), so every rank must build -- and therefore evict -- at the same calls:
+    this cache only ever sees the sharded calls, which all ranks issue in the same order with the same keys, whereas the
+    rank-local `detect()` / `predict()` calls of one rank can no longer push a sharded detector out on that rank alone."""
+    cache = net.__dict__.setdefault("_sharded_detectors", OrderedDict()) if sharded else _detector_cache(net)
     det = cache.get(key)
     if det is None:
         while len(cache) >= DETECTOR_CACHE_MAX:

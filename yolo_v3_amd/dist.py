@@ -220,8 +220,8 @@ def detect_sharded(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, u
     x, b_pad, spans = take_shard(imgs, rank, world, local_shard)
     x = x.to(dev, non_blocking=True).float().contiguous()
     key = ("sharded", b_pad, tuple(x.shape[1:]), float(obj_conf_thr), float(nms_thr), bool(use_nms), int(cap), dtype,
-           net.math_mode, bool(force_collective), id(group))
+           net.math_mode, bool(force_collective), group)        # (the group OBJECT: an id() can be reused after a group is collected)
     sd = cached_detector(net, key, lambda: ShardedDetector(net, b_pad, x.shape[2], x.shape[3], obj_conf_thr, nms_thr, use_nms,
-                                                           cap, dtype, group, force_collective))
+                                                           cap, dtype, group, force_collective), sharded=True)
     with torch.no_grad():
         return sd.assemble(sd.run_device(x), spans)                       # assemble: the single host sync

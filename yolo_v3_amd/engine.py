@@ -201,13 +201,17 @@ def batch_split(B, ho, wo, cout_pad, ncu):
 
 
 def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None,
-              batch=None, wino_ws=None, two_lanes=False):
-    """`batch` = (b0, nb): the descriptor covers images b0 .. b0+nb-1 of the [NP][B,...] plane tensors (plane dtypes only)."""
+              batch=None, wino_ws=None, two_lanes=False, wino_always=False):
+    """`batch` = (b0, nb): the descriptor covers images b0 .. b0+nb-1 of the [NP][B,...] plane tensors (plane dtypes only).
+    `wino_always`: YV3_OPT_WINO_ALWAYS (``net.winograd = "always"``: the Winograd form on every eligible layer, whatever the
+    tile count)."""
     sp = pc.spec
     d = ConvDesc()
     d.options, d.big_tile_min = tuning_options()
     if two_lanes:
         d.options |= _ffi.OPT_TWO_LANES
+    if wino_always:
+        d.options |= _ffi.OPT_WINO_ALWAYS
     for i, v in enumerate((os.environ.get("YV3_TUNE", "") or "0").split(",")[:4]):
         d.tune[i] = int(v or 0)
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
@@ -319,7 +323,7 @@ class Plan:
                 split = batch_split(B, ho, wo, pc.cout_pad, ncu)
             for part in ([None] if split is None else [(0, split[0]), (split[0], split[1])]):
                 descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace, batch=part,
-                                       wino_ws=self.wino_ws, two_lanes=two_lanes))
+                                       wino_ws=self.wino_ws, two_lanes=two_lanes, wino_always=engine.wino_always))
                 self.desc_spec.append(i)
             if y is not None:
                 self.layer_out[pc.spec.name] = y
@@ -402,6 +406,28 @@ class Plan:
     def bytes_allocated(self):
         return sum(t.numel() * t.element_size() for t in self._keep)
 
+    def forms(self):
+        """Per descriptor of the launch sequence (``descs[first_desc:]``): (conv spec index, form) with form = 0 direct /
+        1 Winograd, as the library decides it on the current device (``yv3_conv2d_form``: tile count, lane count, CU count)."""
+        lib = _ffi.lib()
+        out = []
+        for j in range(self.first_desc, self.n_desc):
+            f = lib.yv3_conv2d_form(ctypes.byref(self.descs[j]))
+            if f < 0:
+                _ffi.check(f, "yv3_conv2d_form")
+            out.append((self.desc_spec[j], int(f)))
+        return out
+
+    def executed_mac_factor(self):
+        """{conv spec index: matrix multiplications executed / direct-form multiplications} for the launch sequence:
+        16/36 for a launch that takes the Winograd F(2x2,3x3) form (even pictures; the tile grid of an odd picture is
+        ceil(H/2) x ceil(W/2), so e.g. 13x13 executes 16 * 49 per 9 * 169 direct), 1 otherwise."""
+        out = {}
+        for j, (si, f) in zip(range(self.first_desc, self.n_desc), self.forms()):
+            d = self.descs[j]
+            out[si] = (16.0 * ((d.H + 1) // 2) * ((d.W + 1) // 2)) / (9.0 * d.H * d.W) if f == 1 else 1.0
+        return out
+
 
 class Engine:
     """Packs a YoloNet's parameters and runs the static plan."""
@@ -433,18 +459,43 @@ class Engine:
         self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_BATCH_SPLIT") == "1"))
         # Winograd F(2x2,3x3) for the 3x3 stride-1 layers with >= 256 input channels (fp16-plane mode; csrc/winograd.hip)
         # (default on: the library uses it per launch when the tile count suits it, yv3_conv_desc.w_wino; YV3_WINO=0 / net.winograd = False: never)
-        self.winograd = bool(getattr(net, "winograd", os.environ.get("YV3_WINO", "1") != "0"))
+        # net.winograd = "always" (YV3_WINO=always): on every eligible layer whatever the tile count (parity tests of the form itself)
+        wino = getattr(net, "winograd", None)
+        if wino is None:
+            env = os.environ.get("YV3_WINO", "1")
+            wino = "always" if env == "always" else env != "0"
+        self.wino_always = wino == "always" or bool(os.environ.get("YV3_WINO_ALWAYS"))
+        self.winograd = bool(wino)
+        # net.deterministic = True: ONE switch for "the same image gives the same bits at every batch size, batch position and lane
+        # count": direct one-tile-per-workgroup kernels only (no per-launch Winograd choice, no stream-K split tiles); `Detector`
+        # then also runs a single lane.  Costs ~10 % at bs=64.
+        self.deterministic = bool(getattr(net, "deterministic", os.environ.get("YV3_DETERMINISTIC") == "1"))
+        if self.deterministic:
+            self.winograd, self.wino_always, self.stream_k = False, False, False
 
     # -- weights
     def _param_tensors(self):
         """Every tensor the packed weights depend on, in spec order.  The module objects are resolved once (75
         ``get_submodule`` path walks cost ~1.4 ms -- per forward, and exposed in every synchronous ``detect()`` call); the
         tensors themselves are re-read from them each time, so re-assigned parameters are still seen."""
-        mods = self.__dict__.get("_mods")
-        if mods is None:
-            mods = self._mods = [self.net.get_submodule(sp.name) for sp in self.specs]
+        slots = self.__dict__.get("_mod_slots")
+        if slots is not None:
+            # a cached module is only trusted while its parent still holds the SAME object under the same name (75 dict
+            # look-ups, ~10 us): a replaced submodule (net.pre_det1.mlist[6] = nn.Conv2d(...)) is re-resolved -- and, its
+            # tensors being new objects, changes the signature
+            for reg, key, m in slots:
+                if reg.get(key) is not m:
+                    slots = None
+                    break
+        if slots is None:
+            slots = []
+            for sp in self.specs:
+                parent, _, leaf = sp.name.rpartition(".")
+                pm = self.net.get_submodule(parent) if parent else self.net
+                slots.append((pm._modules, leaf, pm._modules[leaf]))
+            self._mod_slots = slots
         out = []
-        for m in mods:                               # (straight from the modules' dicts: nn.Module.__getattr__ is slow)
+        for _, _, m in slots:                        # (straight from the modules' dicts: nn.Module.__getattr__ is slow)
             if isinstance(m, torch.nn.Conv2d):
                 pr = m._parameters
                 out.append(pr["weight"])
@@ -509,6 +560,7 @@ class Engine:
         self.packed = None
         self._sig = None
         self._plans = {}
+        self.__dict__.pop("_mod_slots", None)
 
     # -- plans
     def drop_plan(self, B, H, W):
@@ -596,8 +648,9 @@ class Engine:
             plan.flags_host.zero_()
             plan.flags_event = None
             if flag_value & 2:
-                raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out "
-                                    "(stream-K is opt-in: unset net.stream_k / YV3_SK and report)")
+                raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out (the stream-K schedule is automatic "
+                                    "for single images and opt-in otherwise: set net.stream_k = False or YV3_SK=0 -- or "
+                                    "net.deterministic = True -- to disable it, and report)")
             raise _ffi.Yv3Error(self.OVERFLOW_MSG_BF16 if self.dtype == BF16 else self.OVERFLOW_MSG)
 
     def forward(self, x, dets=None):

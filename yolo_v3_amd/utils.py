@@ -52,6 +52,7 @@ class PostProcessor:
         self._ws = None
         self._ws_n = 0
         self._out = out
+        self._owns_out = out is None
         if out is not None:
             assert out.is_contiguous() and tuple(out.shape) == (B, self.cap, 7)
 
@@ -61,6 +62,11 @@ class PostProcessor:
             self._ws = torch.empty(lib.yv3_postproc_nms_workspace_bytes(self.B, max_n, self.C), dtype=torch.uint8, device=self.device)
             self._ws_n = max_n
         return self._ws
+
+    def bytes_allocated(self):
+        """Device bytes this processor owns (candidate keys, NMS workspace, its own output / counts)."""
+        own = [self.cand, self._ws, self.counts] + ([self._out] if self._owns_out else [])
+        return sum(t.numel() * t.element_size() for t in own if t is not None)
 
     def filter(self, dets, conf_thr, is_eval, prob=False):
         mode = (_ffi.PP_EVAL if is_eval else 0) | (_ffi.PP_PROB if prob else 0)
@@ -106,17 +112,29 @@ def boxes_to_list(out, counts_host, B, max_cand):
     return [host[b, :nkeep[b]].clone() if ncand[b] else torch.Tensor() for b in range(B)]
 
 
-_PP_CACHE = OrderedDict()       # (device, B, N, C, max_cand) -> PostProcessor; eval mode's key buffer is N*C*8 B per image
-_PP_CACHE_MAX = 2
+_PP_CACHE = OrderedDict()       # (device, stream, thread, B, N, C, max_cand) -> PostProcessor
+_PP_CACHE_MAX = 4               # entries ...
+_PP_CACHE_MAX_BYTES = 4 << 30   # ... and bytes (eval mode: 8*N*C B of keys per image + B*nmax*ceil(nmax/64)*8 B of NMS masks)
+
+
+def clear_postproc_cache():
+    """Drop the `postprocessing()` buffers kept for repeated calls (they can reach GBs in eval mode)."""
+    _PP_CACHE.clear()
 
 
 def _cached_postprocessor(B, N, num_classes, device, max_cand):
-    key = (str(device), B, N, num_classes, max_cand)
+    """One PostProcessor per (shape, STREAM, THREAD): `postprocessing()` hands the same candidate / count / output / workspace
+    buffers to every call with the same key, so calls that may overlap -- other streams, other threads -- must not share
+    an entry.  Bounded by entry count and by bytes, least recently used first out."""
+    import threading
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), B, N, num_classes, max_cand)
     pp = _PP_CACHE.get(key)
     if pp is None:
-        while len(_PP_CACHE) >= _PP_CACHE_MAX:
+        pp = PostProcessor(B, N, num_classes, device, max_cand=max_cand)
+        _PP_CACHE[key] = pp
+        while len(_PP_CACHE) > 1 and (len(_PP_CACHE) > _PP_CACHE_MAX or
+                                      sum(q.bytes_allocated() for q in _PP_CACHE.values()) > _PP_CACHE_MAX_BYTES):
             _PP_CACHE.popitem(last=False)
-        pp = _PP_CACHE[key] = PostProcessor(B, N, num_classes, device, max_cand=max_cand)
     else:
         _PP_CACHE.move_to_end(key)
     return pp
