@@ -539,3 +539,36 @@ def test_eval_detect_fused_equals_two_phase(sw1_stream):
     assert len(net._detectors) <= dmod.DETECTOR_CACHE_MAX
     detect(net, x, 80, 0.5, 0.4)
     assert sum(1 for k, v in net._detectors.items() if ids.get(k) in (None, id(v))) == len(net._detectors)
+
+
+def _trained_weights_path():
+    cands = [os.environ.get("YV3_TRAINED_WEIGHTS"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "weights", "yolov3.weights"),
+             os.path.join(os.getcwd(), "weights", "yolov3.weights")]
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.mark.skipif(_trained_weights_path() is None, reason="no trained darknet weight file (YV3_TRAINED_WEIGHTS / weights/yolov3.weights): "
+                    "yolov3.weights is not available offline (reference README.md:24-30)")
+def test_trained_weights_modes_agree(golden_dir):
+    """Only when a TRAINED weight file is present: the default fp16-plane mode has never seen one (every fixture uses synthetic
+    weights).  The three fp32-class modes must agree with each other within 1e-4 on the dog image (exact-fp32 MFMA without its
+    Winograd stage as the yardstick), give the same candidate set, and the default mode must not report saturation."""
+    from yolo_v3_amd import YoloNet
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    x = _input(g, "dog416").cuda()
+    net = YoloNet((416, 416)).eval()
+    net.loadWeight(_trained_weights_path(), "darknet")
+    net = net.cuda()
+    out = {}
+    for mode in (_ffi.F32, _ffi.F32X3, _ffi.F32H2):
+        net.math_mode = mode
+        with torch.no_grad():
+            out[mode] = net.forward_cat(x).cpu()              # (raises Yv3Error if an fp16 plane saturated)
+    for mode in (_ffi.F32X3, _ffi.F32H2):
+        e = assert_close_rel(out[mode], out[_ffi.F32], TOL, "trained weights: mode %d vs exact fp32" % mode)
+        print("trained weights: mode %d vs exact fp32: %.3g" % (mode, e))
+    sc = {m: (d[..., 5:] * d[..., 4:5]).amax(-1) > 0.5 for m, d in out.items()}
+    assert torch.equal(sc[_ffi.F32H2], sc[_ffi.F32]) and int(sc[_ffi.F32].sum()) > 0

@@ -31,8 +31,15 @@ namespace {
 // YV3_WABL (timing ablations of the Winograd GEMM stage's ping-pong loop, results INVALID; tools/timeline_wino.py):
 //   1 no DMA pieces in the compute segment   2 both k-steps' fragments read in the load segment (no SPLIT)
 //   4 no fold at the end of a position       8 no MFMAs (fragments kept alive)
+//   16 every DMA source is the tile's FIRST chunk (L1/L2-hot lines: no memory-system bandwidth / latency in the loop)
+//   32 pixel-side rows paired into full 128-byte lines (row r reads half (r & 1) of line r >> 1: the traffic of 128-byte rows)
 #ifndef YV3_WABL
 #define YV3_WABL 0
+#endif
+// YV3_PPX (schedule experiments of the ping-pong loop, results valid): 1 s_setprio(1) around the compute segment's MFMAs
+//   2 Winograd stage: both k-steps' fragments in the load segment (no SPLIT)   4 the same for every 32x64-wave-tile kernel
+#ifndef YV3_PPX
+#define YV3_PPX 0
 #endif
 
 // PP ("ping-pong"): the 8 waves of the workgroup form two groups of four (one wave per SIMD each) that run
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 aoff2[q] = (((long long)b * p.H + ho) * p.W + wo) * (p.Cin - p.Cup) + sslot;
             } else {
                 aoff[q] = (((long long)b * p.H + ho * p.stride) * p.W + wo * p.stride) * p.Cin + sslot;
+                if constexpr (WINO && (YV3_WABL & 32)) aoff[q] = (long long)(mm >> 1) * p.Cin + (mm & 1) * 32 + sslot;
             }
         }
         const int n0w = n0 + BROWS * wid;                      // first weight row of this wave (a wave's rows never straddle a packed tile)
@@ -165,6 +173,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
             for (int q = 0; q < AQ; ++q) ap[q] += ainc[q];
         }
         wbp = p.w + ((btile + kc) * NP) * (long long)(p.tb * PBK) + bin;
+        if constexpr (WINO && (YV3_WABL & 16)) {
+            wbp = p.w + (btile * NP) * (long long)(p.tb * PBK) + bin;
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) { ap[q] = p.x + aoff[q]; aps[q] = p.xs; }
+        }
         c0 += PBK;
         if (c0 == p.Cin) { c0 = 0; if (WINO) ++kw; else if (++kw == 3) { kw = 0; ++kh; } }
     };
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         const int grp = YV3_PP_GRP(wid);
         // 32x64 wave tiles (128x128 workgroup tile): the compute segment is only 12 MFMAs per k-step, so the second
         // k-step's fragments are fetched under the first k-step's MFMAs; measured +5 % there, -5 % on 64x64 wave tiles
-        constexpr bool SPLIT = MT == 1 && !(WINO && (YV3_WABL & 2));
+        constexpr bool SPLIT = MT == 1 && !(WINO && ((YV3_WABL & 2) || (YV3_PPX & 2))) && !(YV3_PPX & 4);
 #ifdef YV3_TIMELINE
         unsigned long long tl_load = 0, tl_b1 = 0, tl_comp = 0, tl_b2 = 0, tl_pro = 0, tl_epi = 0, tl_t = tl_entry;
         int tl_items = 0, tl_chunks = 0;
@@ -324,6 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- compute segment: MFMAs from registers, the DMA pieces of chunk kc+D between them
                 // (SPLIT: plus the second k-step's fragment reads)
+                if constexpr ((YV3_PPX & 1) != 0) __builtin_amdgcn_s_setprio(1);
                 if constexpr (SPLIT) {
 #pragma unroll
                     for (int ks = 1; ks < KS; ++ks)
@@ -349,6 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((YV3_PPX & 1) != 0) __builtin_amdgcn_s_setprio(0);
                 if constexpr (WINO) {
                     if (--wleft == 0 && !(YV3_WABL & 4)) {                         // end of a transform position: Y += (A^T x A^T)[.][xi] * M
                         wleft = p.Cin / PBK;
