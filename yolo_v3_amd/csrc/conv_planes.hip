@@ -21,9 +21,16 @@
 // Replaces the same reference call sites as conv_igemm_f32.hip (darknet.py:43-44, :52-53, :118,
 // :161-162).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_planes_common.h"
 
 namespace {
+
+// s_waitcnt lgkmcnt(N) as the BUILTIN (vmcnt / expcnt left at their maxima): hipcc's own wait insertion understands it, so after it the
+// compiler knows those LDS reads have returned.  Behind an inline-asm wait it does not -- and then puts a full lgkmcnt(0) in front of
+// the next use of the registers, AFTER younger reads were issued (the second k-step's fragments requested at the start of a compute
+// segment: ~320 exposed cycles per chunk, round 4).
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8)); }
 
 #ifndef YV3_PP_GRP
 #define YV3_PP_GRP(wid) ((wid) >> 2)
@@ -53,10 +60,15 @@ namespace {
 // WINO (ping-pong kernels, NP = 2): Winograd F(2x2,3x3) GEMM stage (csrc/winograd.hip): the K loop walks the 16 transform
 // positions (Cin/32 chunks each, operand matrix xi * xi_stride into the V planes); at the end of a position the product
 // accumulators are folded into the tile's four outputs with the coefficients of A^T x A^T (0 / +-1: exact) and cleared.
+// ROLL (single-phase kernels, ring of >= 3 stages): the chunk's ONE barrier sits between its two k-steps, and the first k-step's
+// fragments of chunk k+1 are read under the second k-step's MFMAs of chunk k -- a rolling software pipeline over the chunk
+// boundary, so that no LDS read latency is ever exposed behind a barrier (the plain loop reads a chunk's first fragments right
+// after its barrier and waits for them before the first MFMA).
 template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, bool K3, bool DUAL, bool OUT_F32, bool PP = false, bool SK = false, int MINW = 1, int MTG = 0,
-          bool WINO = false>
+          bool WINO = false, bool ROLL = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const ConvParamsP p) {
-    static_assert(!WINO || (PP && !K3 && !DUAL && !OUT_F32 && NP == 2), "Winograd stage: ping-pong fp16-plane kernel");
+    static_assert(!WINO || ((PP || ROLL) && !K3 && !DUAL && !OUT_F32 && NP == 2), "Winograd stage: ping-pong or rolling fp16-plane kernel");
+    static_assert(!ROLL || (!PP && !SK && NSTAGE >= 3), "rolling loop: single-phase kernel with a ring of >= 3 stages");
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile: WTM pixels x WTN channels
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -247,7 +259,26 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         const int grp = YV3_PP_GRP(wid);
         // 32x64 wave tiles (128x128 workgroup tile): the compute segment is only 12 MFMAs per k-step, so the second
         // k-step's fragments are fetched under the first k-step's MFMAs; measured +5 % there, -5 % on 64x64 wave tiles
-        constexpr bool SPLIT = MT == 1 && !(WINO && ((YV3_WABL & 2) || (YV3_PPX & 2))) && !(YV3_PPX & 4);
+        // (round 4: NOT for the Winograd stage -- with its 4-deep ring both k-steps' fragments in the load segment are 2-4 % faster per
+        // layer, profiles/r04c_pp_schedule_*.log)
+        constexpr bool SPLIT = MT == 1 && !(YV3_PPX & 4);
+        // ordered SPLIT (fp16 planes): the second k-step's fragments are requested in the order its MFMAs consume them (x_hi, w_lo..,
+        // x_lo, w_hi..) and hipcc waits for them one by one (partial lgkmcnt: it can, now that the load segment's wait is the builtin):
+        // a wave's ds_read_b128 return 1 KB per ~36 cycles (tools/probes/lds_read_rate.hip), so six of them take ~320 cycles -- longer
+        // than the first k-step's six MFMAs
+        constexpr bool OSPLIT = SPLIT && NP == 2 && !(YV3_PPX & 8);
+        // ... the first OS_EARLY of them already in the load segment (then the load segment's 8 reads take about as long as the partner's 12
+        // MFMAs, and the 4 left for the compute segment have returned before the second k-step starts)
+        constexpr int OS_EARLY = 2;
+        auto os_order = [](int q) -> int {          // fragment index (read_frag) of the q-th operand in consumption order
+            if (q < MT) return NT * NP + q * NP;                       // x_hi[j]
+            q -= MT;
+            if (q < NT) return q * NP + 1;                             // w_lo[i]
+            q -= NT;
+            if (q < MT) return NT * NP + q * NP + 1;                   // x_lo[j]
+            q -= MT;
+            return q * NP;                                             // w_hi[i]
+        };
 #ifdef YV3_TIMELINE
         unsigned long long tl_load = 0, tl_b1 = 0, tl_comp = 0, tl_b2 = 0, tl_pro = 0, tl_epi = 0, tl_t = tl_entry;
         int tl_items = 0, tl_chunks = 0;
@@ -326,10 +357,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 for (int ks = 0; ks < (SPLIT ? 1 : KS); ++ks)
 #pragma unroll
                     for (int f = 0; f < NF; ++f) read_frag(ks, f);
+                if constexpr (OSPLIT) {                                            // the second k-step's first operands: x_hi, w_lo of weight tile 0
+#pragma unroll
+                    for (int q = 0; q < OS_EARLY; ++q) read_frag(1, os_order(q));
+                }
                 const bool more = kc + D < k1;
                 if (more) dma_prepare(kc + D, nxt);
                 if (kc + D - 1 < k1) wait_vmcnt<(D - 2) * G>(); else wait_vmcnt<0>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_lgkmcnt<0>();
                 __builtin_amdgcn_sched_barrier(0);
                 TL_MARK(tl_load);
                 __builtin_amdgcn_s_barrier();
@@ -338,7 +373,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 // ---- compute segment: MFMAs from registers, the DMA pieces of chunk kc+D between them
                 // (SPLIT: plus the second k-step's fragment reads)
                 if constexpr ((YV3_PPX & 1) != 0) __builtin_amdgcn_s_setprio(1);
-                if constexpr (SPLIT) {
+                if constexpr (OSPLIT) {
+                    static_assert(!OSPLIT || KS == 2, "ordered SPLIT: two k-steps");
+#pragma unroll
+                    for (int q = OS_EARLY; q < NF; ++q) { read_frag(1, os_order(q)); __builtin_amdgcn_sched_barrier(0); }
+                } else if constexpr (SPLIT) {
 #pragma unroll
                     for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
@@ -346,7 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (SPLIT && ks == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                    if (SPLIT && !OSPLIT && ks == 1) { wait_lgkmcnt<0>(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                     for (int t = 0; t < NMF; ++t)                                  // rotate over the accumulators: no back-to-back RAW
 #pragma unroll
@@ -482,6 +521,116 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
 #endif
         return;
     }
+    if constexpr (ROLL) {
+        static_assert(KS == 2, "rolling loop: two k-steps per chunk");
+        // chunk 0 has landed and is visible; its first k-step's fragments go to registers
+        if (D <= p.nk) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int f = 0; f < NF; ++f) read_frag(0, f);
+        static_assert(NP <= 2, "rolling loop: one or two planes");
+        constexpr int NMF = NP == 2 ? 3 : 1;          // MFMAs per (weight tile, pixel tile, k-step)
+        constexpr int TOT = NMF * NU;                 // MFMAs of one k-step block
+        constexpr int RH = TOT >= 4 ? TOT / 2 : TOT;  // the other buffer's NF fragment reads follow the first RH of them
+        // MFMAs of k-step `ks` (registers frag[ks]), rotating over the accumulators; `rd`: fragment reads into frag[ko] from `st`
+        // behind them; `pieces`: this chunk's DMA pieces too
+        auto kstep_block = [&](auto ks_c, auto ko_c, bool rd, bool pieces) {
+            constexpr int ks = decltype(ks_c)::value, ko = decltype(ko_c)::value;
+#pragma unroll
+            for (int t = 0; t < NMF; ++t)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int i = u / MT, j = u % MT;
+                    const bf16x8v* wf = &frag[ks][i * NP];
+                    const bf16x8v* xf = &frag[ks][NT * NP + j * NP];
+                    if constexpr (NP == 2) acc[i][j] = PlaneOps<2>::mfma(wf[t == 0 ? 1 : 0], xf[t == 1 ? 1 : 0], acc[i][j]);
+                    else acc[i][j] = PlaneOps<1>::mfma(wf[0], xf[0], acc[i][j]);
+                    const int mi = t * NU + u;
+                    if (rd && mi < RH) {
+#pragma unroll
+                        for (int f = mi * NF / RH; f < (mi + 1) * NF / RH; ++f) read_frag(ko, f);
+                    }
+                    if (pieces) {
+#pragma unroll
+                        for (int g = mi * G / TOT; g < (mi + 1) * G / TOT; ++g) dma_piece(g);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+#ifdef YV3_TIMELINE
+        unsigned long long rl_prep = 0, rl_b0 = 0, rl_wait = 0, rl_bar = 0, rl_b1 = 0, rl_fold = 0, rl_t = __builtin_amdgcn_s_memtime();
+#define RL_MARK(acc_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - rl_t; rl_t = t_; } while (0)
+#else
+#define RL_MARK(acc_) do {} while (0)
+#endif
+        int cur = 0, nxt = D % NSTAGE;
+        for (int kc = 0; kc < p.nk; ++kc) {
+            const bool more = kc + D < p.nk;
+            const bool next = kc + 1 < p.nk;
+            st = lds + cur * STAGE;
+            if (more) dma_prepare(kc + D, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            RL_MARK(rl_prep);
+            // ---- first k-step: MFMAs on frag[0]; behind the first half of them the second k-step's fragment reads, behind all of
+            // them the DMA pieces of chunk kc+D.  (Reads go out AFTER an MFMA, never before the block's first one: the wait
+            // hipcc puts in front of a block's first MFMA is lgkmcnt(0), which must not catch reads issued for the next block.)
+            kstep_block(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, true, more);
+            RL_MARK(rl_b0);
+            // ---- the chunk's barrier: my pieces of chunk kc+1 have landed, my reads of this chunk's stage are complete
+            if (next) {
+                if (more) wait_vmcnt<(D - 1) * G>(); else wait_vmcnt<0>();
+                wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                RL_MARK(rl_wait);
+                __builtin_amdgcn_s_barrier();
+                RL_MARK(rl_bar);
+                __builtin_amdgcn_sched_barrier(0);
+                st = lds + (cur + 1 == NSTAGE ? 0 : cur + 1) * STAGE;
+            }
+            // ---- second k-step: MFMAs on frag[1]; behind the first half of them the NEXT chunk's first-k-step fragment reads
+            kstep_block(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, next, false);
+            RL_MARK(rl_b1);
+            if constexpr (WINO) {
+                if (--wleft == 0) {                                                // end of a transform position: Y += (A^T x A^T)[.][xi] * M
+                    wleft = p.Cin / PBK;
+                    const int xr = wxi >> 2, xc = wxi & 3;
+                    ++wxi;
+                    const float r0 = xr < 3 ? 1.f : 0.f, r1 = xr == 0 ? 0.f : (xr == 1 ? 1.f : -1.f);
+                    const float q0 = xc < 3 ? 1.f : 0.f, q1 = xc == 0 ? 0.f : (xc == 1 ? 1.f : -1.f);
+                    const float sc[4] = {r0 * q0, r0 * q1, r1 * q0, r1 * q1};
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const float mv = acc[i][j][e];
+#pragma unroll
+                                for (int o = 0; o < 4; ++o) yac[o][i][j][e] = fmaf(mv, sc[o], yac[o][i][j][e]);
+                                acc[i][j][e] = 0.f;
+                            }
+                }
+            }
+            RL_MARK(rl_fold);
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+        }
+#ifdef YV3_TIMELINE
+        if (blockIdx.x == 100 && lane == 0 && p.alpha && WINO) {     // debug build only: cycle split of one workgroup -> alpha[0..]
+            float* dbg = const_cast<float*>(p.alpha) + wid * 8;
+            const float n_ = (float)p.nk;
+            dbg[0] = rl_prep / n_; dbg[1] = rl_b0 / n_; dbg[2] = rl_wait / n_; dbg[3] = rl_bar / n_; dbg[4] = rl_b1 / n_; dbg[5] = rl_fold / n_;
+            dbg[6] = n_; dbg[7] = (float)(rl_t - tl_entry);
+        }
+#endif
+        if constexpr (WINO) {
+            __syncthreads();                                                       // every wave is done with the last stage
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
+        } else epilogue_store<NP, BM, BN, WM, WN, OUT_F32, true, EMTG>(acc, p, lds, m0, n0, wid, lane);
+        return;
+    }
 #ifdef YV3_TIMELINE
     unsigned long long tl_wait = 0, tl_bar = 0, tl_body = 0, tl_prev = 0, tl_dma = 0;
 #endif
@@ -582,7 +731,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
     epilogue_store<NP, BM, BN, WM, WN, OUT_F32, true, EMTG>(acc, p, lds, m0, n0, wid, lane);
 }
 
-template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1, int MTG = 0>
+template <int NP, int BM, int BN, int WM, int WN, int NSTAGE, int MINW = 1, int MTG = 0, bool ROLL = false>
 int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_pp, hipStream_t s) {
     const int mtiles = (p.M + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
@@ -618,7 +767,7 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_
         if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
         if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
     } \
-    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, false, false, MINW, MTG>), grid, block, lds, s, q); } while (0)
+    hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, false, false, MINW, MTG, false, ROLL>), grid, block, lds, s, q); } while (0)
     if (out_f32) {
         if (k3 || dual) return YV3_ESHAPE;                   // fp32 outputs are the 1x1 head convs
         YV3_LAUNCH(false, false, true);
@@ -758,7 +907,16 @@ static int launch_wino(const yv3_conv_desc* d, ConvParamsP p, hipStream_t s) {
         hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, true, 1, 0, true>), dim3((unsigned)num_cu), dim3(512), lds, s, p);
     } else {
         p.ws = nullptr; p.wsflags = nullptr; p.ws_bytes = 0;
-        hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, false, 1, 0, true>), grid, dim3(512), lds, s, p);
+        // two-group ping-pong loop (default) or the rolling single-phase loop (one barrier per chunk, fragment reads spread under the
+        // MFMAs; tune[1] bit 1: A/B measurements -- bit-identical, equal speed: profiles/r04d_wino_roll_vs_pingpong_ab.log; the same stage
+        // on FOUR waves with 64x64 wave tiles and the rolling loop was 1.4x slower, profiles/r04f_wino_4waves_roll_ab.log)
+#ifndef YV3_WINO_ROLL
+#define YV3_WINO_ROLL 0
+#endif
+        if (((p.tune[1] >> 1) & 1) != YV3_WINO_ROLL)
+            hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, false, false, 1, 0, true, true>), grid, dim3(512), lds, s, p);
+        else
+            hipLaunchKernelGGL((conv_planes_kernel<2, BM, BN, 4, 2, NS, false, false, false, true, false, 1, 0, true>), grid, dim3(512), lds, s, p);
     }
     YV3_CHECK_LAUNCH();
     return 0;
@@ -862,6 +1020,9 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         if (np == 1 && force == 5) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2>(p, k3, dual, out_f32, false, s);
         // 256x256 tile on eight waves (128x64 wave tiles), one workgroup per CU, single-phase loop
         if (np == 1 && force == 6 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, false, s); }
+        // (code 8: the 256x256 tile with the rolling loop; code 9: 4-deep ring)
+        if (np == 1 && force == 8 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
+        if (np == 1 && force == 9 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 4, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         // short-K 1x1 layers (K <= 512: 8-16 chunks per tile, mostly prologue / epilogue): two independent 4-wave workgroups
         // per CU (128x128 tiles, 2-deep ring) hide each other's IO -- in the network at bs=64 the step gains 0.8 %
@@ -883,6 +1044,22 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // @13 702 -> 846.  Below one tile per CU (512->1024 @19 at bs=16: 184 tiles, 1x1 layers at 38 / 19) the 8-wave ping-pong
         // tile wins by 7...30 % (twice the waves per tile).  A 256x256 / 8-wave tile (code 6) loses to both at these sizes.
         // (tune[2] > 0: threshold override for A/B measurements)
+        // (code 7: the same tile with the rolling loop -- barrier between the k-steps, next chunk's first fragments read under the MFMAs)
+        if (np == 1 && force == 7) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2, true>(p, k3, dual, out_f32, false, s);
+        // Round 4 (tools/tile_ab.py, profiles/r04d_bf16_roll_ab.log, r04j_bf16_tiles_ab.log): the 3x3 layers take the ROLLING loop on that
+        // tile (+2...6 %; the 1x1 layers lose 1-3 % on it and keep the plain loop) -- and a 256x256 tile on eight waves (128x64 wave tiles,
+        // one workgroup per CU, rolling loop: 32 KB of DMA per 128 MFMAs instead of 24 KB per 64 -- the L2 -> LDS path delivers 62 B/clk/CU,
+        // tools/probes/dma_rate.hip, and was the 256x128 tile's co-bottleneck) when its tile count fills the chip's last round:
+        // 676 tiles (128->256 @52x52 bs=64) +8 %, 172 (512->1024 @13x13 bs=64) +15 %, 182 (256->512 @38x38 bs=16) +14 %; but 338
+        // (1.32 rounds) -7 %, 361 -6 %, 92 -28 %.  Rule: r = tiles / CUs; r >= 0.6 up to one round, r / ceil(r) >= 0.8 beyond.
+        if (np == 1 && force == 0 && k3 && !out_f32 && npad % 256 == 0 && !(p.tune[1] & 8)) {
+            const long long t256 = ((M + 255) / 256) * (npad / 256);
+            const long long ncu = yv3_num_cu();
+            const bool fill = t256 <= ncu ? t256 * 10 >= 6 * ncu : t256 * 10 >= 8 * ((t256 + ncu - 1) / ncu) * ncu;
+            if (fill) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
+        }
+        if (np == 1 && force == 0 && k3 && blocks256 >= (p.tune[2] > 0 ? p.tune[2] : 256) && !out_f32 && !(p.tune[1] & 8))
+            return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2, true>(p, k3, dual, out_f32, false, s);
         if (np == 1 && force == 0 && blocks256 >= (p.tune[2] > 0 ? p.tune[2] : 256) && !out_f32) return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2>(p, k3, dual, out_f32, false, s);
         if (np == 1 && use_pp && force == 0 && blocks256 >= big_min) return launch_cfg<1, 256, 128, 4, 2, 6>(p, k3, dual, out_f32, true, s);
         if (blocks256 >= (sk_ok ? 256 : big_min)) return YV3_CFG(256, 128, 4, 2, 2);
