@@ -28,12 +28,19 @@ def main():
     fam = collections.OrderedDict()
     for di, c in disp.items():
         n = c["name"]
+        targs = [a.strip() for a in n.split("conv_planes_kernel<")[1].split(">")[0].split(",")] if "conv_planes_kernel<" in n else []
+        # template <NP, BM, BN, WM, WN, NSTAGE, K3, DUAL, OUT_F32, PP, SK, MINW, MTG, WINO, ROLL>
+        wino = len(targs) > 13 and targs[13] == "true"
+        roll = len(targs) > 14 and targs[14] == "true"
+        tile = ",".join(targs[:5]) if targs else ""
         key = ("wino_input_kernel (Winograd input transform)" if "wino_input" in n else
-               "conv_planes_kernel<2,128,128,...,WINO> (Winograd GEMM stage)" if ("conv_planes_kernel<2, 128, 128" in n and ", true>(" in n) else
-               "conv_planes_kernel<1,256,128,2,2> (bf16, four waves, 128x64 wave tiles)" if "conv_planes_kernel<1, 256, 128, 2, 2" in n else
-               "conv_planes_kernel<1,256,128,4,2> (bf16, 8-wave ping-pong)" if "conv_planes_kernel<1, 256, 128, 4, 2" in n else
-               "conv_planes_kernel<2,256,128> (3x3 / 1x1, 8-wave ping-pong)" if "conv_planes_kernel<2, 256, 128" in n else
-               "conv_planes_kernel<2,*> other tiles" if "conv_planes_kernel<2" in n else
+               "conv_planes_kernel<2,128,128,...,WINO> (Winograd GEMM stage)" if wino else
+               "conv_planes_kernel<1,256,256,2,4,ROLL> (bf16, 8 waves, 128x64 wave tiles, rolling loop)" if tile == "1,256,256,2,4" else
+               "conv_planes_kernel<1,256,128,2,2,ROLL> (bf16, four waves, rolling loop)" if tile == "1,256,128,2,2" and roll else
+               "conv_planes_kernel<1,256,128,2,2> (bf16, four waves, 128x64 wave tiles)" if tile == "1,256,128,2,2" else
+               "conv_planes_kernel<1,256,128,4,2> (bf16, 8-wave ping-pong)" if tile == "1,256,128,4,2" else
+               "conv_planes_kernel<2,256,128> (3x3 / 1x1, 8-wave ping-pong)" if tile.startswith("2,256,128") else
+               "conv_planes_kernel<2,*> other tiles" if targs and targs[0] == "2" else
                "conv_planes_kernel (other modes)" if "conv_planes" in n else
                "conv_front" if "front" in n else "conv_res64" if "conv_res64" in n else "conv_1x1" if "conv1x1" in n else
                "conv_igemm_f32_kernel" if "conv_igemm" in n else "conv0" if "conv0" in n else
