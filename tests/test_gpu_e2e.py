@@ -572,3 +572,30 @@ def test_trained_weights_modes_agree(golden_dir):
         print("trained weights: mode %d vs exact fp32: %.3g" % (mode, e))
     sc = {m: (d[..., 5:] * d[..., 4:5]).amax(-1) > 0.5 for m, d in out.items()}
     assert torch.equal(sc[_ffi.F32H2], sc[_ffi.F32]) and int(sc[_ffi.F32].sum()) > 0
+
+
+def test_postprocessing_cache_is_per_stream_and_clearable():
+    """`postprocessing()` keeps its candidate / count / output / workspace buffers for repeated calls; calls that may
+    overlap (another stream) must not share them, and the cache can be dropped."""
+    from yolo_v3_amd import utils as yu, clear_postproc_cache
+    clear_postproc_cache()
+    g = torch.Generator().manual_seed(11)
+    d = torch.rand(2, 300, 9, generator=g)
+    d[..., 0:2] = d[..., 0:2] * 100 + 50
+    d[..., 2:4] = d[..., 2:4] * 60 + 20
+    dg = d.cuda()
+    want = oc.postprocess(d, 4, 0.3, 0.4)
+    r0 = postprocessing(dg, 4, 0.3, 0.4)
+    assert len(yu._PP_CACHE) == 1
+    postprocessing(dg, 4, 0.3, 0.4)
+    assert len(yu._PP_CACHE) == 1                                   # same stream, same shape: reused
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        r1 = postprocessing(dg, 4, 0.3, 0.4)
+    assert len(yu._PP_CACHE) == 2                                   # another stream: its own buffers
+    for a, b, c in zip(r0, r1, want):
+        assert torch.equal(a, c) and torch.equal(b, c)
+    assert all(pp.bytes_allocated() > 0 for pp in yu._PP_CACHE.values())
+    clear_postproc_cache()
+    assert len(yu._PP_CACHE) == 0

@@ -249,3 +249,46 @@ def test_division_free_iou_compare_is_exact():
             for _ in range(abs(step)):
                 x = np.nextafter(x, np.float32(np.inf if step > 0 else -np.inf))
             assert np.array_equal((x / union) > thr, x.astype(np.float64) > mid * union.astype(np.float64))
+
+
+def test_sharded_detectors_have_their_own_cache():
+    """building a sharded detector contains a collective, so every rank must build -- and evict -- at
+    the same calls.  `cached_detector(sharded=True)` therefore keeps its own least-recently-used cache that rank-local
+    `detect()` calls (which differ from rank to rank) can neither fill nor evict."""
+    import importlib
+    dmod = importlib.import_module("yolo_v3_amd.detect")             # (the package exports the FUNCTION detect under that name)
+
+    class Net:                       # only the attribute dict is used
+        pass
+    net = Net()
+    built = []
+
+    def make(tag):
+        return lambda: built.append(tag) or tag
+    assert dmod.cached_detector(net, ("sharded", 32), make("s32"), sharded=True) == "s32"
+    for i in range(dmod.DETECTOR_CACHE_MAX + 2):                       # a rank-local burst of other shapes on THIS rank only
+        dmod.cached_detector(net, ("local", i), make("l%d" % i))
+    assert len(net._detectors) == dmod.DETECTOR_CACHE_MAX and ("sharded", 32) not in net._detectors
+    n = len(built)
+    assert dmod.cached_detector(net, ("sharded", 32), make("again"), sharded=True) == "s32" and len(built) == n   # still there: no rebuild
+    for i in range(dmod.DETECTOR_CACHE_MAX):                           # sharded calls evict among themselves (same order on every rank)
+        dmod.cached_detector(net, ("sharded", 100 + i), make("s%d" % i), sharded=True)
+    assert ("sharded", 32) not in net._sharded_detectors and len(net._sharded_detectors) == dmod.DETECTOR_CACHE_MAX
+
+
+def test_engine_reresolves_a_replaced_submodule():
+    """the engine caches the 75 conv modules it resolved; a REPLACED submodule (new objects, new tensors) must be
+    seen by the very next signature -- the cache is validated by identity against the parents' module dicts on every call."""
+    from yolo_v3_amd import engine
+    net = YoloNet((416, 416)).eval()
+    eng = engine.Engine(net, _ffi.F32H2)
+    before = eng._param_tensors()
+    old = net.pre_det1.mlist[6]
+    net.pre_det1.mlist[6] = torch.nn.Conv2d(old.in_channels, old.out_channels, 1)
+    after = eng._param_tensors()
+    assert len(after) == len(before)
+    new_w = net.pre_det1.mlist[6].weight
+    assert any(t is new_w for t in after) and not any(t is old.weight for t in after)
+    assert eng._signature() != tuple((t.data_ptr(), t._version) for t in before)
+    eng.invalidate()
+    assert "_mod_slots" not in eng.__dict__

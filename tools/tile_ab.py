@@ -36,7 +36,9 @@ for name in names:
         y = engine.alloc_act(B, ho, wo, cout, dt, "cuda")
         y.zero_()
         d = engine.make_desc(pc, x, y, B, H, H, r, dtype=dt)
-        d.options = (d.options & ~(0xff << 8)) | (v << 8)
+        d.options = (d.options & ~(0xff << 8)) | ((v % 100) << 8)
+        if v >= 200:
+            d.options |= _ffi.OPT_K3S1                                    # codes 2xx: the kw-tap-reuse kernel (conv_planes_k3s1.hip)
         descs.append(d); outs.append(y)
         for _ in range(3):
             _ffi.check(lib.yv3_conv2d(d, st))
