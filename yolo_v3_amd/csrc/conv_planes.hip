@@ -48,6 +48,10 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { __builtin_amdg
 #ifndef YV3_PPX
 #define YV3_PPX 0
 #endif
+// YV3_WINO_EPI4: the Winograd tile's four outputs through epilogue_store_wino4 (1) or four epilogue_store passes (0; A/B builds)
+#ifndef YV3_WINO_EPI4
+#define YV3_WINO_EPI4 1
+#endif
 
 // PP ("ping-pong"): the 8 waves of the workgroup form two groups of four (one wave per SIMD each) that run
 // half a chunk out of phase: while one group issues a chunk's 24 MFMAs from registers, the other reads its
@@ -501,9 +505,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                 }
             }
             if constexpr (WINO) {
+                if constexpr (MT == 1 && NP == 2 && YV3_WINO_EPI4) epilogue_store_wino4<BM, BN, WM, WN>(yac, p, lds, m0, n0, wid, lane);
+                else {
 #pragma unroll
-                for (int o = 0; o < 4; ++o)
-                    epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
+                    for (int o = 0; o < 4; ++o)
+                        epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
+                }
             } else epilogue_store<NP, BM, BN, WM, WN, OUT_F32, false, EMTG>(acc, p, lds, m0, n0, wid, lane);
             TL_MARK(tl_epi);
 #ifdef YV3_TIMELINE
@@ -625,9 +632,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
 #endif
         if constexpr (WINO) {
             __syncthreads();                                                       // every wave is done with the last stage
+            if constexpr (MT == 1 && NP == 2 && YV3_WINO_EPI4) epilogue_store_wino4<BM, BN, WM, WN>(yac, p, lds, m0, n0, wid, lane);
+            else {
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
+                for (int o = 0; o < 4; ++o)
+                    epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
+            }
         } else epilogue_store<NP, BM, BN, WM, WN, OUT_F32, true, EMTG>(acc, p, lds, m0, n0, wid, lane);
         return;
     }

@@ -353,4 +353,136 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     }
 }
 
+// ---- epilogue of a Winograd launch: the tile's FOUR outputs Y[wi][wj] (yac[2 wi + wj]) in one pass structure.  Same arithmetic,
+// element by element, as four epilogue_store<..., WINO> calls (bit-identical), but: the BN parameters are loaded once, the tile-row
+// -> pixel map (two integer divisions per row) is computed once, and the residual rows of output o+1 are requested while output o
+// is processed -- four serialised residual round trips per tile were 6-12 % of a Winograd layer's time
+// (profiles/r04p_wino_epilogue_io_ablation.log).  fp16 planes, 32-row wave tiles.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_store_wino4(f32x16 (&yac)[4][BN / WN / 32][BM / WM / 32], const ConvParamsP& p,
+                                                     unsigned char* lds, int m0, int n0, int wid, int lane) {
+    constexpr int NP = 2;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int NT = WTN / 32;
+    static_assert(WTM == 32, "one 32-row accumulator block per wave");
+    constexpr int EP = WTN + 4, LPR = WTN / 8, RPP = 64 / LPR, NPASS = 32 / RPP;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const bool has_alpha = p.alpha != nullptr;
+    const float* asrc = has_alpha ? p.alpha : p.beta;
+    f32x4 alv[NT][4], bev[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * lhi;
+            const int nn = n < p.Cout ? n : 0;
+            bev[i][g] = *reinterpret_cast<const f32x4*>(p.beta + nn);
+            alv[i][g] = *reinterpret_cast<const f32x4*>(asrc + nn);
+        }
+    // tile row -> pixel of output (0, 0), once per pass row; bit 0: row stored at all, bit 1: row 2 ty + 1 inside, bit 2: column 2 tx + 1 inside
+    const int ncol = n0 + wn * WTN + (lane % LPR) * 8;
+    long long pxb[NPASS];
+    int okb[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int m = m0 + wm * WTM + ps * RPP + lane / LPR;
+        pxb[ps] = 0; okb[ps] = 0;
+        if (m < p.M && ncol < p.Cout) {
+            const int tt = p.wth * p.wtw;
+            const int b = m / tt;
+            const int rem = m - b * tt;
+            const int ty = rem / p.wtw, tx = rem - ty * p.wtw;
+            pxb[ps] = ((long long)b * p.wH + 2 * ty) * p.wW + 2 * tx;
+            okb[ps] = 1 | (2 * ty + 1 < p.wH ? 2 : 0) | (2 * tx + 1 < p.wW ? 4 : 0);
+        }
+    }
+    auto opix = [&](int ps, int o) -> long long {
+        const int need = 1 | ((o >> 1) ? 2 : 0) | ((o & 1) ? 4 : 0);
+        return (okb[ps] & need) == need ? pxb[ps] + (o >> 1) * p.wW + (o & 1) : -1;
+    };
+    const bool use_res = p.res && !(p.tune[3] & 2);
+    u32x4 rres[2][NPASS][NP];
+    auto fetch_res = [&](int o, int buf) {
+        if (use_res) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const long long px = opix(ps, o);
+                const long long off = px >= 0 ? px * p.Cout + ncol : 0;                    // clamped, unused if out of range
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) rres[buf][ps][pl] = *reinterpret_cast<const u32x4*>(p.res + pl * p.ys + off);
+            }
+        }
+    };
+    fetch_res(0, 0);
+    if (!has_alpha) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) alv[i][g] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    const float slope = p.act == YV3_ACT_LEAKY ? 0.1f : 1.f;
+    float* tile = reinterpret_cast<float*>(lds) + wid * (32 * EP);
+    float amax = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        // the previous output's rows of this wave's LDS tile have been read
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = i * 32 + 8 * g + 4 * lhi;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = fmaf(yac[o][i][0][4 * g + q], alv[i][g][q], bev[i][g][q]);
+                    v[q] = __builtin_fmaxf(t, slope * t);
+                }
+                *reinterpret_cast<f32x4*>(tile + l31 * EP + nl) = v;
+            }
+        if (o < 3) fetch_res(o + 1, (o + 1) & 1);                 // in flight while this output is split and stored
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + lane / LPR;
+            const int cg = (lane % LPR) * 8;
+            const long long px = opix(ps, o);
+            if (px < 0) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + r * EP + cg + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const long long off = px * p.Cout + ncol;
+            if (p.res) {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const u32x4 q4 = rres[o & 1][ps][pl];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { v[2 * h] += PlaneOps<2>::lo(q4[h]); v[2 * h + 1] += PlaneOps<2>::hi(q4[h]); }
+                }
+            }
+            u16* yo = (u16*)p.y + off;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[2 * h]), __builtin_fabsf(v[2 * h + 1])));
+            u32x4 qh, ql;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                v[2 * h] = __builtin_amdgcn_fmed3f(v[2 * h], -65504.f, 65504.f);
+                v[2 * h + 1] = __builtin_amdgcn_fmed3f(v[2 * h + 1], -65504.f, 65504.f);
+                qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
+                ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
+            }
+            if (!(p.tune[3] & 1)) {
+                *reinterpret_cast<u32x4*>(yo) = qh;
+                *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
+            } else { asm volatile("" :: "v"(qh), "v"(ql)); }
+        }
+    }
+    if (p.flags && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(p.flags, 1);
+}
+
 }  // namespace
