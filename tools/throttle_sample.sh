@@ -2,8 +2,8 @@
 # Throttle / power / clock readout while the headline bench loops ("power-limited" was inference, not evidence).
 # Tries every readout this image offers; whatever works is logged verbatim.
 export TMPDIR=/tmp
-O=gpurun_out/r03_throttle_status_during_bench.txt; : > $O
-python bench.py --no-extras --no-cpu-baseline --no-live-traffic --steps 4000 --warmup 5 > gpurun_out/r03_throttle_bench.json 2>/dev/null &
+O=gpurun_out/${TAG:-r04}_throttle_status_during_bench.txt; : > $O
+python bench.py --no-extras --no-cpu-baseline --no-live-traffic --steps 4000 --warmup 5 > gpurun_out/${TAG:-r04}_throttle_bench.json 2>/dev/null &
 BP=$!
 sleep 25
 for i in 1 2 3; do
@@ -23,5 +23,5 @@ done
 wait $BP
 echo "=== idle, after the run" >> $O
 timeout 20 amd-smi metric -g 0 --power --clock --throttle 2>&1 | head -80 >> $O
-tail -c 400 gpurun_out/r03_throttle_bench.json | head -c 400 >> $O
+tail -c 400 gpurun_out/${TAG:-r04}_throttle_bench.json | head -c 400 >> $O
 wc -l $O; grep -iE "throttl|violation|POWER|socket_power|clk|CAP" $O | head -60

@@ -35,6 +35,12 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { __builtin_amdg
 #ifndef YV3_PP_GRP
 #define YV3_PP_GRP(wid) ((wid) >> 2)
 #endif
+// Measurement switches.  Run time (yv3_conv_desc.tune[], set by tools/ through YV3_TUNE=a,b,c,d; 0 = the shipped behaviour):
+//   tune[1] bit 0  no two-workgroup tile for the short-K 1x1 layers      bit 1  Winograd stage: rolling instead of ping-pong main loop
+//           bit 3  bf16: round-3 tile selection (no rolling loop, no 256x256 tile)
+//   tune[2]        bf16: threshold (256x128 tiles) from which the four-wave tile is used
+//   tune[3] bit 0  epilogue without its stores   bit 1  without its residual loads   (results INVALID: IO ablation)
+// Compile time (A/B builds through tools/build_variant.sh):
 // YV3_WABL (timing ablations of the Winograd GEMM stage's ping-pong loop, results INVALID; tools/timeline_wino.py):
 //   1 no DMA pieces in the compute segment   2 both k-steps' fragments read in the load segment (no SPLIT)
 //   4 no fold at the end of a position       8 no MFMAs (fragments kept alive)
