@@ -32,6 +32,7 @@ extern "C" {
 #define YV3_ESHAPE   (-2)        /* shape not supported by the kernel family (see function) */
 #define YV3_EWORKSPACE (-3)      /* workspace too small                                     */
 #define YV3_EDTYPE   (-4)        /* unknown dtype code                                      */
+#define YV3_ERCCL    (-5)        /* yv3_gather_boxes: librccl not found, or ncclAllGather failed */
 
 /* Tensor / math modes.  "Plane" tensors are NP bf16 planes [NP][B,H,W,C] (plane stride B*H*W*C).   */
 #define YV3_F32  0               /* fp32 NHWC tensors, exact fp32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -331,13 +332,18 @@ int yv3_correct_boxes(const float* boxes, int B, int cap, int ld, const int* cou
                       int img_w, int img_h, int is_letterbox, int out_xyxy, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Multi-GPU.  There is deliberately no gather-boxes entry point here (SURVEY.md section 8b lists one in its minimum set): the
- * path's only collective -- ONE all-gather of the [B_local, cap + 1, 7] fp32 payload, i.e. the [B, cap, 7] output of
- * yv3_postproc_nms plus one row per image carrying its int32 candidate count, kept count and the status word
- * (yv3_conv_desc.flags), bit-cast -- is issued by the host side through torch.distributed (backend "nccl" = RCCL over xGMI),
- * as BASELINE.json's north_star prescribes; a C entry point would only wrap ncclAllGather on a communicator the Python side
- * owns.  The payload layout is yolo_v3_amd/dist.py:pack_payload / unpack_payload.
+ * Multi-GPU ("yv3_gather_boxes(comm, ...)").  The reference is single-GPU; images are independent
+ * (utils.py:152), so the sharded path has exactly ONE exchange: an all-gather of every rank's [b_local, rows, 7] fp32 payload --
+ * rows = cap + 1: the [b_local, cap, 7] output of yv3_postproc_nms plus one row per image carrying its int32 candidate count,
+ * kept count and the status word (yv3_conv_desc.flags), bit-cast; layout = yolo_v3_amd/dist.py:pack_payload / unpack_payload --
+ * into gathered [world * b_local, rows, 7], rank order.
+ *   rccl_comm: an ncclComm_t owned by the caller (ncclCommInitRank ...); stream: hipStream_t the collective is enqueued on.
+ * One ncclAllGather over RCCL/xGMI, nothing else; no allocation, no synchronisation.  libyv3.so does not link librccl: the symbol is
+ * resolved at the first call (from the process if RCCL is already loaded, else librccl.so.1 / librccl.so), YV3_ERCCL if absent.
+ * The Python product (`detect_sharded`) issues the same collective through torch.distributed (backend "nccl" = RCCL), whose
+ * communicator cannot be handed out; this entry point is for hosts that own their communicator.
  * ------------------------------------------------------------------------------------------ */
+int yv3_gather_boxes(const float* payload, float* gathered, int b_local, int rows, void* rccl_comm, void* stream);
 
 #ifdef __cplusplus
 }

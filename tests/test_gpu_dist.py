@@ -94,3 +94,40 @@ def test_bench_two_ranks_on_this_gpu_over_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["entry"].startswith("ShardedDetector.run_device") and "[8, 513, 7]" in out["config"]["collective"]
     assert out["value"] > 0 and "gather" in out["stages_ms"] and len(out["config"]["boxes_kept_first_images"]) == 4
+
+
+def test_yv3_gather_boxes_is_one_rccl_allgather():
+    """The C entry point of the path's one exchange (include/yv3.h: yv3_gather_boxes) on a communicator the CALLER owns:
+    a world-1 ncclComm_t made with RCCL's own API (ctypes on the librccl torch ships), the payload `pack_payload` builds, one
+    ncclAllGather on the current stream -- the gathered tensor must equal the payload bit for bit and unpack to the inputs."""
+    import ctypes
+    from yolo_v3_amd import _ffi
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0 and comm.value
+    try:
+        B, cap = 5, 9
+        boxes = torch.rand(B, cap, 7, device="cuda")
+        cand = torch.arange(B, dtype=torch.int32, device="cuda") * 3
+        kept = torch.arange(B, dtype=torch.int32, device="cuda")
+        payload = ydist.pack_payload(boxes, cand, kept, torch.tensor([4], dtype=torch.int32, device="cuda"))
+        out = torch.zeros_like(payload)
+        lib = _ffi.lib()
+        _ffi.check(lib.yv3_gather_boxes(payload.data_ptr(), out.data_ptr(), B, cap + 1, comm, _ffi.stream_ptr()), "yv3_gather_boxes")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), payload.view(torch.int32))
+        gb, meta = ydist.unpack_payload(out)
+        assert torch.equal(gb, boxes) and meta[:, 0].tolist() == cand.tolist() and meta[:, 1].tolist() == kept.tolist() and set(meta[:, 2].tolist()) == {4}
+        assert lib.yv3_gather_boxes(payload.data_ptr(), out.data_ptr(), B, cap + 1, None, _ffi.stream_ptr()) == -1     # YV3_EINVAL: no communicator
+    finally:
+        rccl.ncclCommDestroy(comm)

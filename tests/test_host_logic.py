@@ -292,3 +292,14 @@ def test_engine_reresolves_a_replaced_submodule():
     assert eng._signature() != tuple((t.data_ptr(), t._version) for t in before)
     eng.invalidate()
     assert "_mod_slots" not in eng.__dict__
+
+
+def test_gather_boxes_rejects_bad_arguments_without_touching_rccl():
+    """yv3_gather_boxes validates before it resolves librccl: null communicator / non-positive sizes -> YV3_EINVAL (no GPU, no RCCL here)."""
+    lib = _ffi.lib()
+    buf = (ctypes.c_float * 8)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.yv3_gather_boxes(p, p, 1, 1, None, None) == -1
+    assert lib.yv3_gather_boxes(p, p, 0, 1, p, None) == -1
+    assert lib.yv3_gather_boxes(None, p, 1, 1, p, None) == -1
+    assert b"RCCL" in lib.yv3_error_string(-5)

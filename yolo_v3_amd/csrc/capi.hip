@@ -15,6 +15,7 @@ extern "C" const char* yv3_error_string(int code) {
         case YV3_ESHAPE: return "shape not supported by this kernel family";
         case YV3_EWORKSPACE: return "workspace too small";
         case YV3_EDTYPE: return "unknown dtype";
+        case YV3_ERCCL: return "RCCL: librccl.so not found or ncclAllGather failed";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown yv3 error";
     }
 }
