@@ -20,8 +20,8 @@ extern "C" const char* yv3_error_string(int code) {
     }
 }
 
-static int check_desc(const yv3_conv_desc* d) {
-    if (!d || !d->x || !d->w || !d->beta || (!d->y && !d->dec_out)) return YV3_EINVAL;
+static int check_desc(const yv3_conv_desc* d, bool need_output = true) {
+    if (!d || !d->x || !d->w || !d->beta || (need_output && !d->y && !d->dec_out)) return YV3_EINVAL;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->cin <= 0 || d->cout <= 0) return YV3_EINVAL;
     if (d->k != 1 && d->k != 3) return YV3_ESHAPE;
     if (d->stride != 1 && d->stride != 2) return YV3_ESHAPE;
@@ -51,7 +51,7 @@ extern "C" int yv3_conv2d(const yv3_conv_desc* d, void* stream) {
 }
 
 extern "C" int yv3_conv2d_form(const yv3_conv_desc* d) {
-    const int rc = check_desc(d);
+    const int rc = check_desc(d, false);            // (a fused-decode head may not have its output bound yet)
     if (rc) return rc;
     if (d->dtype == YV3_F32) return yv3_conv2d_f32_form(d);
     if (d->dtype == YV3_F32_F16X2) return yv3_conv2d_planes_form(d, 2);
