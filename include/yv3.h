@@ -316,6 +316,13 @@ int yv3_postproc_nms(const float* dets, int B, int N, int num_class, float nms_t
 int yv3_letterbox(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
                   void* stream);
 
+/* The same resampling with the box geometry GIVEN (box_w x box_h pixels of the resized image at (box_x, box_y) on the 128-grey
+ * canvas): the evaluation pipeline's letterbox (transforms.py:144-209, IaaLetterbox: box at ((out_w-box_w)//2, (out_h-box_h)//2) --
+ * one pixel off utils.letterbox_transforms' out//2 - box//2 when the parities differ) and its plain `iaa.Scale(dim)` (evaluate.py:213:
+ * box == canvas, bicubic).  Same cv2 caveat as yv3_letterbox.  YV3_ESHAPE if the box does not fit the canvas. */
+int yv3_letterbox_ex(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
+                     int box_w, int box_h, int box_x, int box_y, void* stream);
+
 /* Replaces load_image(mode='resize') (utils.py:68-71): cv2.resize(img, (out_w,out_h)) with the default INTER_LINEAR
  * (OpenCV's fixed-point 8-bit path; an exact 2x2 shrink is INTER_AREA, as in cv::resize), /255, HWC -> CHW. */
 int yv3_resize_linear(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,

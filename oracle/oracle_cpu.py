@@ -416,6 +416,32 @@ def letterbox_image(img, dim):
     return torch.from_numpy((canvas.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())
 
 
+def iaa_letterbox_params(image_shape, new_h, new_w):
+    """reference transforms.py:196-205 (IaaLetterbox._compute_height_width_pad): the EVALUATION pipeline's letterbox geometry --
+    (resize_w, resize_h, x_pad, y_pad) with the pads floored from (new - resized) / 2 (utils.letterbox_transforms uses
+    new // 2 - resized // 2: one pixel more when `new` is even and `resized` odd)."""
+    img_h, img_w = image_shape[0:2]
+    ratio = min(new_w / img_w, new_h / img_h)
+    resize_w, resize_h = int(img_w * ratio), int(img_h * ratio)
+    return resize_w, resize_h, (new_w - resize_w) // 2, (new_h - resize_h) // 2
+
+
+def iaa_letterbox_image(img, dim):
+    """evaluate.py:211 `Compose([IaaAugmentations([IaaLetterbox(dim)]), ToTensor()])` for one image (transforms.py:144-172,25-43):
+    imgaug's `imresize_single_image(..., interpolation="cubic")` is cv2.resize(INTER_CUBIC) (third-party, absent: restated above,
+    parity with cv2 UNPINNED), np.pad with 128, /255, CHW.  img: uint8 [H,W,3]; dim = (w,h)."""
+    rw, rh, xp, yp = iaa_letterbox_params(img.shape, dim[1], dim[0])
+    canvas = np.full((dim[1], dim[0], 3), 128, dtype=np.uint8)
+    canvas[yp:yp + rh, xp:xp + rw] = cv_resize_cubic_u8(img, rw, rh)
+    return torch.from_numpy((canvas.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())
+
+
+def iaa_scale_image(img, dim):
+    """evaluate.py:213 `iaa.Scale(dim)` + ToTensor: imgaug's default interpolation is "cubic" -> cv2.resize(img, dim, INTER_CUBIC)."""
+    out = cv_resize_cubic_u8(img, dim[0], dim[1])
+    return torch.from_numpy((out.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())
+
+
 def resize_image(img, dim):
     """reference utils.py:68-71, mode='resize': cv2.resize(img, dim) (INTER_LINEAR), /255, CHW."""
     out = cv_resize_linear_u8(img, dim[0], dim[1])

@@ -599,3 +599,40 @@ def test_postprocessing_cache_is_per_stream_and_clearable():
     assert all(pp.bytes_allocated() > 0 for pp in yu._PP_CACHE.values())
     clear_postproc_cache()
     assert len(yu._PP_CACHE) == 0
+
+
+@pytest.mark.parametrize("lb", [True, False])
+def test_generate_results_file_matches_manual_composition(tmp_path, lb):
+    """reference evaluate.py:208-219 (``generate_results_file``) end to end: image files listed in a text file -> the evaluation
+    pipeline's input preparation on the GPU (IaaLetterbox / iaa.Scale + ToTensor) -> eval-mode detection at the reference's 0.005 /
+    0.45 -> COCO-results file.  The file equals, byte for byte, the one the writer produces from batches prepared by the ORACLE's
+    restatement of that input preparation and pushed through ``predict_and_process`` by hand (SW-eval weights)."""
+    from PIL import Image
+    from yolo_v3_amd import evaluate
+    net = load_sw1_net(synth.eval_weight_stream()).cuda()
+    shapes = [(333, 500), (480, 640), (415, 833), (416, 416), (300, 200)]
+    paths = []
+    for i, (h, w) in enumerate(shapes):
+        im = (synth.images(1, 416, 800 + i)[0].transpose(1, 2, 0) * 255).astype(np.uint8)
+        im = np.ascontiguousarray(np.tile(im, (3, 3, 1))[:h, :w])
+        p = str(tmp_path / ("COCO_val2014_%012d.png" % (100 + i)))
+        Image.fromarray(im).save(p)                                         # PNG: lossless, decoder-independent
+        paths.append(p)
+    txt = str(tmp_path / "list.txt")
+    open(txt, "w").write("\n".join(paths) + "\n")
+    out = str(tmp_path / "results.json")
+    n = evaluate.generate_results_file(net, txt, ["c%d" % k for k in range(80)], out, 2, (416, 416), is_letterbox=lb)
+    js = json.load(open(out))
+    assert n == len(js) > 0 and {e["image_id"] for e in js} <= set(range(100, 105))
+    # manual composition with oracle-prepared inputs
+    want = str(tmp_path / "want.json")
+    prep = oc.iaa_letterbox_image if lb else oc.iaa_scale_image
+    with evaluate.open_json_pred_writer(want, None, lb) as wr:
+        for i in range(0, len(paths), 2):
+            imgs = [evaluate.read_image_rgb(p) for p in paths[i:i + 2]]
+            sample = {"img": torch.stack([prep(im, (416, 416)) for im in imgs]), "org_img": imgs, "img_path": paths[i:i + 2]}
+            evaluate.predict_and_process([sample], net, 80, wr)
+    assert open(out).read() == open(want).read()
+    for e in js:
+        h, w = shapes[e["image_id"] - 100]
+        assert -1e-3 <= e["bbox"][0] <= w and -1e-3 <= e["bbox"][1] <= h

@@ -723,3 +723,27 @@ def test_winograd_f32_conv_vs_fp64(cin, cout, B, H, W, res):
     direct = _run_mode(mc, x, mode, r)
     print("fp32 winograd %s: err vs fp64 %.3g (direct kernel %.3g)" % ((cin, cout, B, H, W), e, float(rel_err(direct, ref).max())))
     assert_close_rel(out, direct, 2e-5, "fp32 winograd vs direct")
+
+
+def test_eval_letterbox_and_scale_vs_oracle():
+    """The evaluation pipeline's input preparation on the GPU (SURVEY 8f-1 eval variant; evaluate.py:211,213): ``IaaLetterbox(dim)``
+    (box at ((out - box) // 2): one pixel off the utils rule for odd boxes) and ``iaa.Scale(dim)`` (plain bicubic resize), bit for bit
+    against the oracle's restatement (cv2 resampling parity UNPINNED as for yv3_letterbox; geometry pinned by the reference)."""
+    from yolo_v3_amd import letterbox_batch, letterbox_transforms
+    shapes = [(500, 333), (415, 833), (452, 602), (37, 53), (1080, 1920), (416, 416)]
+    imgs = [(synth.uniform01(61 + i, 9, h * w * 3).reshape(h, w, 3) * 255).astype(np.uint8) for i, (h, w) in enumerate(shapes)]
+    for dim in ((416, 416), (608, 416)):
+        batch, trans = letterbox_batch(imgs, dim, variant="eval")
+        for i, im in enumerate(imgs):
+            ref = oc.iaa_letterbox_image(im, dim)
+            assert torch.equal(batch[i].cpu(), ref), "eval letterbox image %d dim %s: %d values differ" % (i, dim, int((batch[i].cpu() != ref).sum()))
+            assert trans[i].tolist()[:4] == list(oc.iaa_letterbox_params(im.shape, dim[1], dim[0]))
+        sc, _ = letterbox_batch(imgs, dim, variant="scale")
+        for i, im in enumerate(imgs):
+            assert torch.equal(sc[i].cpu(), oc.iaa_scale_image(im, dim))
+    # the 333 x 500 image: box 277 wide -> x offset 69 here, 70 under utils.letterbox_transforms
+    b416, tr = letterbox_batch(imgs[:1], (416, 416), variant="eval")
+    assert tr[0].tolist()[:4] == [277, 416, 69, 0] and letterbox_transforms((333, 500), (416, 416))[2] == 70
+    assert not torch.equal(b416[0].cpu(), oc.letterbox_image(imgs[0], (416, 416)))
+    with pytest.raises(_ffi.Yv3Error):                                     # a box that does not fit the canvas is refused
+        _ffi.check(_ffi.lib().yv3_letterbox_ex(b416.data_ptr(), 8, 8, b416.data_ptr(), 416, 416, 417, 10, 0, 0, _ffi.stream_ptr()), "yv3_letterbox_ex")

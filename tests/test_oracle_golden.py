@@ -191,3 +191,23 @@ def test_cv_resize_restatement_known_answers():
     assert lb.shape == (3, 416, 416) and np.all(lb[:, :52] == grey) and np.all(lb[:, 364:] == grey)
     box = oc.cv_resize_cubic_u8(pic, 416, 312).astype(np.float32) / np.float32(255)
     assert np.array_equal(lb[:, 52:364], box.transpose(2, 0, 1))
+
+
+def test_eval_letterbox_geometry_and_totensor_vs_reference(golden_dir):
+    """SURVEY 8f-1, eval variant: the oracle's (and the product's) restatement of ``IaaLetterbox._compute_height_width_pad``
+    (transforms.py:196-205) equals the REFERENCE's output on 75 (shape, dim) cases -- incl. those where it differs by one pixel from
+    ``utils.letterbox_transforms`` -- and ``uint8 -> float32 / 255`` is the reference's ToTensor map bit for bit (oracle/make_golden_eval_letterbox.py)."""
+    import os
+    from yolo_v3_amd import utils as yu
+    g = np.load(os.path.join(golden_dir, "eval_letterbox.npz"))
+    differs = 0
+    for h, w, dw, dh, rw, rh, xp, yp in g["geometry"].tolist():
+        assert oc.iaa_letterbox_params((h, w, 3), dh, dw) == (rw, rh, xp, yp)
+        assert yu.iaa_letterbox_params((h, w), dh, dw) == (rw, rh, xp, yp)
+        bw, bh, bx, by, _ = oc.letterbox_transforms((w, h), (dw, dh))
+        assert (bw, bh) == (rw, rh)
+        differs += (bx, by) != (xp, yp)
+    assert differs > 0                                    # the two pad rules really are different functions
+    ramp = g["ramp"]
+    mine = (ramp.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1)
+    assert mine.dtype == np.float32 and np.array_equal(mine, g["ramp_tensor"])

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "yv3_cxcywh_to_xyxy": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
     "yv3_iou_matrix": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "yv3_letterbox": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "yv3_letterbox_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_resize_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "yv3_correct_boxes": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "yv3_gather_boxes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -166,6 +166,21 @@ extern "C" int yv3_letterbox(const unsigned char* img_hwc, int H, int W, float* 
     return 0;
 }
 
+// The same kernel with the box geometry given by the caller: the evaluation pipeline's letterbox places the resized image at
+// ((out_w - box_w) // 2, (out_h - box_h) // 2) (reference transforms.py:196-205, IaaLetterbox._compute_height_width_pad), which differs
+// from utils.letterbox_transforms' out//2 - box//2 by one pixel when out and box have different parities; and `iaa.Scale(dim)`
+// (evaluate.py:213) is the box == canvas case (a plain bicubic resize).
+extern "C" int yv3_letterbox_ex(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w,
+                                int box_w, int box_h, int box_x, int box_y, void* stream) {
+    if (!img_hwc || !out_chw || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return YV3_EINVAL;
+    if (box_w <= 0 || box_h <= 0 || box_x < 0 || box_y < 0 || box_x + box_w > out_w || box_y + box_h > out_h) return YV3_ESHAPE;
+    const double scale_x = 1.0 / ((double)box_w / W), scale_y = 1.0 / ((double)box_h / H);
+    hipLaunchKernelGGL(letterbox_kernel, dim3(yv3_ceil_div((long long)out_h * out_w, 256)), dim3(256), 0, (hipStream_t)stream,
+                       img_hwc, H, W, out_chw, out_h, out_w, box_w, box_h, box_x, box_y, scale_x, scale_y);
+    YV3_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int yv3_resize_linear(const unsigned char* img_hwc, int H, int W, float* out_chw, int out_h, int out_w, void* stream) {
     if (!img_hwc || !out_chw || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return YV3_EINVAL;
     const double scale_x = 1.0 / ((double)out_w / W), scale_y = 1.0 / ((double)out_h / H);

@@ -122,3 +122,39 @@ def predict_and_process(data, net, num_classes, batch_handler=None, obj_conf_thr
             if predictions == []:
                 predictions = [torch.Tensor() for _ in sample['img_path']]
             batch_handler.process_batch(sample, predictions)
+
+
+def read_image_rgb(path):
+    """uint8 RGB [H,W,3] of an image file (the reference reads with ``cv2.imread`` + BGR->RGB, evaluate.py:136-137; cv2 is not a
+    dependency here: PIL decodes -- JPEG decoders may differ from OpenCV's by an LSB on some pixels)."""
+    import numpy as np
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+
+
+def generate_results_file(net, target_txt, classes_names, out, bs, dim, is_letterbox=False):
+    """reference evaluate.py:208-219: the COCO-results file of a list of images -- ``target_txt`` is the reference's text file with one
+    image path per line (a list of paths, or of ``(path, uint8 RGB [H,W,3] array)`` pairs, is accepted too).  Per batch of ``bs``
+    images: the evaluation pipeline's input preparation on the GPU (``IaaLetterbox(dim)`` when ``is_letterbox`` else
+    ``iaa.Scale(dim)``, then ``ToTensor``: `utils.letterbox_batch(variant="eval" | "scale")`), eval-mode detection (conf 0.005 / nms
+    0.45) and the writer.  ``dim`` = (w, h).  Returns the number of result entries written."""
+    from .utils import letterbox_batch
+    if isinstance(target_txt, str):
+        with open(target_txt, 'r') as f:
+            items = [line.strip() for line in f.readlines() if line.strip()]
+    else:
+        items = list(target_txt)
+    numclass = len(classes_names)
+
+    def batches():
+        for i in range(0, len(items), bs):
+            chunk = items[i:i + bs]
+            paths = [c if isinstance(c, str) else c[0] for c in chunk]
+            imgs = [read_image_rgb(c) if isinstance(c, str) else c[1] for c in chunk]
+            x, _ = letterbox_batch(imgs, dim, variant="eval" if is_letterbox else "scale")
+            yield {"img": x, "org_img": imgs, "img_path": paths}       # (the writer needs only the ORIGINAL sizes: HWC arrays)
+
+    with open_json_pred_writer(out, classes_names, is_letterbox) as pred_writer:
+        predict_and_process(batches(), net, num_classes=numclass, batch_handler=pred_writer)
+        return pred_writer.entries

@@ -203,12 +203,28 @@ def letterbox_transforms(inner_dim, outer_dim):
     return box_w, box_h, (outer_w // 2) - (box_w // 2), (outer_h // 2) - (box_h // 2), ratio
 
 
-def letterbox_batch(images, dim, device=None):
+def iaa_letterbox_params(image_shape, new_h, new_w):
+    """reference transforms.py:196-205 (``IaaLetterbox._compute_height_width_pad``, the evaluation pipeline's letterbox):
+    ``(resize_w, resize_h, x_pad, y_pad)`` -- pads floored from ``(new - resized) / 2``."""
+    img_h, img_w = image_shape[0:2]
+    ratio = min(new_w / img_w, new_h / img_h)
+    resize_w, resize_h = int(img_w * ratio), int(img_h * ratio)
+    return resize_w, resize_h, (new_w - resize_w) // 2, (new_h - resize_h) // 2
+
+
+def letterbox_batch(images, dim, device=None, variant="utils"):
     """List of uint8 RGB images ([H,W,3] numpy arrays or tensors, any sizes) -> network input batch
     ``[B,3,dim_h,dim_w]`` fp32 in [0,1] on the GPU + per-image transforms ``[B,5]`` (box_w, box_h, x, y, ratio).
 
     One HIP kernel per image does what reference utils.load_image(mode='letterbox') does on the host with cv2
-    (utils.py:44-72): bicubic resize, paste on a 128-grey canvas, /255, HWC -> CHW.  ``dim`` = (w, h)."""
+    (utils.py:44-72): bicubic resize, paste on a 128-grey canvas, /255, HWC -> CHW.  ``dim`` = (w, h).
+
+    ``variant``: ``"utils"`` (default) places the box as ``utils.letterbox_transforms`` does (``out // 2 - box // 2``);
+    ``"eval"`` as the evaluation pipeline's ``IaaLetterbox`` does (``(out - box) // 2``, transforms.py:144-209 --
+    ``evaluate.generate_results_file(..., is_letterbox=True)``); ``"scale"`` is ``iaa.Scale(dim)`` (evaluate.py:213): a plain
+    bicubic resize to ``dim`` (transforms row: the whole canvas, ratio = None)."""
+    if variant not in ("utils", "eval", "scale"):
+        raise ValueError("variant must be 'utils', 'eval' or 'scale'")
     if not torch.cuda.is_available():
         raise _ffi.Yv3Error("no GPU available: this package has no CPU path")
     dev = torch.device(device if device is not None else "cuda")
@@ -225,9 +241,14 @@ def letterbox_batch(images, dim, device=None):
             t = t.to(dev).contiguous()
             keep.append(t)
             H, W = t.shape[0], t.shape[1]
-            _ffi.check(lib.yv3_letterbox(t.data_ptr(), H, W, batch.data_ptr() + b * 3 * out_h * out_w * 4, out_h, out_w,
-                                         _ffi.stream_ptr()), "yv3_letterbox")
-            trans.append(list(letterbox_transforms((W, H), (out_w, out_h))))
+            dst = batch.data_ptr() + b * 3 * out_h * out_w * 4
+            if variant == "utils":
+                _ffi.check(lib.yv3_letterbox(t.data_ptr(), H, W, dst, out_h, out_w, _ffi.stream_ptr()), "yv3_letterbox")
+                trans.append(list(letterbox_transforms((W, H), (out_w, out_h))))
+            else:
+                bw, bh, bx, by = iaa_letterbox_params((H, W), out_h, out_w) if variant == "eval" else (out_w, out_h, 0, 0)
+                _ffi.check(lib.yv3_letterbox_ex(t.data_ptr(), H, W, dst, out_h, out_w, bw, bh, bx, by, _ffi.stream_ptr()), "yv3_letterbox_ex")
+                trans.append([bw, bh, bx, by, min(out_w / W, out_h / H) if variant == "eval" else float("nan")])
         torch.cuda.current_stream().synchronize()      # `keep` (device copies of the inputs) may now be released
     return batch, torch.tensor(trans, dtype=torch.float32)
 
