@@ -453,6 +453,39 @@ def test_conv_bf16_mode_vs_fp64(cin, cout, k, s, B, H, W):
     assert_close_rel(out, ref, 2e-2, "bf16 conv %s" % ((cin, cout, k, s),))
 
 
+@pytest.mark.parametrize("cin,cout,s,B,H,W,selected", [(256, 512, 1, 16, 38, 38, True), (128, 256, 1, 8, 76, 76, True), (256, 512, 2, 3, 37, 41, False),
+                                                        (512, 1024, 1, 64, 13, 13, True), (128, 256, 1, 64, 52, 52, False)])
+def test_conv_bf16_tile_variants_agree_bitwise(cin, cout, s, B, H, W, selected):
+    """bf16 3x3 layers: the per-launch tile choice (conv_planes.hip: 256x128 four-wave / 256x256 / 192x256 eight-wave rolling tiles;
+    the 192-row tile stages 24 pixel rows per wave = one DMA piece and a half) only changes the schedule -- same K order, so every
+    forced tile must equal the library's own choice BIT FOR BIT, M tails included (23104 = 120 x 192 + 64 rows; 3 x 19 x 21 rows);
+    `selected`: shapes whose tile counts make the shipped rule take the 192-row tile (switching the rule off through tune[1] bit 4
+    must change nothing either).  One small shape is also checked against fp64 (same tolerance as test_conv_bf16_mode_vs_fp64)."""
+    m = _rand_cbr(cin, cout, 3, s, seed=cin + cout + 3).cuda()
+    sp = m._spec()
+    pc = engine.pack_conv(m, sp, _ffi.BF16)
+    xn = (torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(5)) * 2 - 0.5).bfloat16().float()
+    x = engine.to_planes(xn.cuda().permute(0, 2, 3, 1).contiguous(), _ffi.BF16)
+    ho, wo = engine.out_hw(H, W, 3, s)
+    outs = {}
+    for code in (0, 7, 8, 11, "rule off"):
+        y = engine.alloc_act(B, ho, wo, cout, _ffi.BF16, "cuda")
+        y.zero_()
+        d = engine.make_desc(pc, x, y, B, H, W, None, dtype=_ffi.BF16)
+        if code == "rule off":
+            d.tune[1] = 16
+        else:
+            d.options = (d.options & ~(0xff << 8)) | (code << 8)
+        _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+        outs[code] = y
+    torch.cuda.synchronize()
+    for code, y in outs.items():
+        assert torch.equal(y, outs[0]), "tile %s differs from the shipped selection" % (code,)
+    if B * ho * wo <= 4096:
+        out = engine.from_planes(outs[11], _ffi.BF16).permute(0, 3, 1, 2).cpu()
+        assert_close_rel(out, _ref_cbr(m.cpu(), xn), 2e-2, "bf16 192-row tile %s" % ((cin, cout, s),))
+
+
 @pytest.mark.parametrize("cin,cout,B,H,W", [(128, 256, 5, 13, 13), (64, 128, 70, 26, 26), (32, 64, 2, 19, 21), (512, 1024, 24, 13, 13), (256, 512, 33, 26, 26)])
 def test_conv_k3s1_tap_reuse_kernel(cin, cout, B, H, W, monkeypatch):
     """Opt-in 3x3/stride-1 kernel that stages ONE activation tile per (kh, channel chunk) and reuses it for

@@ -36,7 +36,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { __builtin_amdg
 #define YV3_PP_GRP(wid) ((wid) >> 2)
 #endif
 // Measurement switches.  Run time (yv3_conv_desc.tune[], set by tools/ through YV3_TUNE=a,b,c,d; 0 = the shipped behaviour):
-//   tune[1] bit 0  no two-workgroup tile for the short-K 1x1 layers      bit 1  Winograd stage: rolling instead of ping-pong main loop
+//   tune[1] bit 0  no two-workgroup tile for the short-K 1x1 layers      bit 1  Winograd stage: rolling instead of ping-pong main loop      bit 4  bf16: no 192-row variant of the 256x256 tile
 //           bit 3  bf16: round-3 tile selection (no rolling loop, no 256x256 tile)
 //   tune[2]        bf16: threshold (256x128 tiles) from which the four-wave tile is used
 //   tune[3] bit 0  epilogue without its stores   bit 1  without its residual loads   (results INVALID: IO ablation)
@@ -87,12 +87,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
     constexpr int B_PLANE = BN * ROWB;
     constexpr int STAGE = NP * (A_PLANE + B_PLANE);
     constexpr int AROWS = BM / NW;                        // pixel rows staged per wave (multiple of 16)
-    constexpr int AQ = AROWS / RPG;                       // global_load_lds per plane per wave, A side
+    constexpr int AQ = (AROWS + RPG - 1) / RPG;           // global_load_lds per plane per wave, A side
+    constexpr int ATAIL = AROWS % RPG;                    // rows of the last one when it is partial (192-row tiles on 8 waves: 24 = 16 + 8)
     constexpr int BROWS = BN / NW;                        // weight rows staged per wave
     constexpr int BQ = BROWS > RPG ? BROWS / RPG : 1;     // global_load_lds per plane per wave, weight side
     constexpr int G = NP * (AQ + BQ);                     // DMA instructions per chunk per wave
     constexpr int D = NSTAGE - 1;                         // prefetch distance in chunks
-    static_assert(AROWS % RPG == 0 && (BROWS <= RPG || BROWS % RPG == 0) && MT >= 1 && NT >= 1, "tile/wave layout");
+    static_assert((ATAIL == 0 || !PP) && (BROWS <= RPG || BROWS % RPG == 0) && MT >= 1 && NT >= 1, "tile/wave layout");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef YV3_TIMELINE
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
 
     // ---- staging, pixel side: wave w moves rows [AROWS*w, AROWS*(w+1)) of every plane, RPG rows per DMA.
     // lane -> (row = lane/4 within the group, physical slot = lane%4); the source is the un-swizzled slot.
-    const int sslot = ((lane & (SLOTS - 1)) ^ ((lane >> 4) & (SLOTS - 1))) * 8;
+    // (the swizzle follows the row's position in the TILE: a wave's first row is a multiple of 16 except with a partial last piece)
+    const int sslot = ((lane & (SLOTS - 1)) ^ (((lane >> 4) + (ATAIL ? (AROWS * wid) >> 2 : 0)) & (SLOTS - 1))) * 8;
     long long aoff[AQ], aoff2[DUAL ? AQ : 1];
     int ahi[K3 ? AQ : 1], awi[K3 ? AQ : 1];
     bool aok[AQ];
@@ -206,8 +208,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
     auto dma_piece = [&](int idx) {
         if (idx < AQ * NP) {
             const int q = idx / NP, pl = idx % NP;
-            __builtin_amdgcn_global_load_lds(GPTR(ap[q] + pl * aps[q]),
-                                             LPTR(dst + pl * A_PLANE + (AROWS * wid + q * RPG) * ROWB), 16, 0, 0);
+            // (a partial last piece: the lanes of the rows beyond this wave's share stay out -- they would land in the next wave's rows)
+            if (ATAIL == 0 || q < AQ - 1 || (lane >> 2) < ATAIL)
+                __builtin_amdgcn_global_load_lds(GPTR(ap[q] + pl * aps[q]),
+                                                 LPTR(dst + pl * A_PLANE + (AROWS * wid + q * RPG) * ROWB), 16, 0, 0);
         } else if (bact) {
             const int q = (idx - AQ * NP) / NP, pl = (idx - AQ * NP) % NP;
             __builtin_amdgcn_global_load_lds(GPTR(wbp + (long long)pl * (p.tb * PBK) + q * (RPG * PBK)),
@@ -776,10 +780,10 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_
                     num_cu <= YV3_SK_MAX_WG && p.ws_bytes >= yv3_conv_workspace_bytes();
     const dim3 sgrid((unsigned)num_cu);
 #define YV3_LAUNCH(K3_, DUAL_, OF_) do { \
-    if constexpr (NP == 1 && WM * WN == 8 && NSTAGE >= 3) { \
+    if constexpr (NP == 1 && WM * WN == 8 && NSTAGE >= 3 && !ROLL) { \
         if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
     } \
-    if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3) { \
+    if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3 && !ROLL) { \
         if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
         if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
     } \
@@ -1039,6 +1043,9 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // (code 8: the 256x256 tile with the rolling loop; code 9: 4-deep ring)
         if (np == 1 && force == 8 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         if (np == 1 && force == 9 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 4, 1, 1, true>(p, k3, dual, out_f32, false, s); }
+        // (code 11: the 192-row variant of the 256x256 rolling tile -- 96x64 wave tiles; also measured and dropped: 192x128 on four waves
+        // and 128x256 on eight, profiles/r04aa_bf16_192row_tiles_ab.log)
+        if (np == 1 && force == 11 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         // short-K 1x1 layers (K <= 512: 8-16 chunks per tile, mostly prologue / epilogue): two independent 4-wave workgroups
         // per CU (128x128 tiles, 2-deep ring) hide each other's IO -- in the network at bs=64 the step gains 0.8 %
@@ -1072,6 +1079,14 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
             const long long t256 = ((M + 255) / 256) * (npad / 256);
             const long long ncu = yv3_num_cu();
             const bool fill = t256 <= ncu ? t256 * 10 >= 6 * ncu : t256 * 10 >= 8 * ((t256 + ncu - 1) / ncu) * ncu;
+            // ... and its 192-row variant (96x64 wave tiles; a wave stages 24 pixel rows = one DMA piece and a half) where that fills the
+            // last round to >= 85 % and 256 rows leave it below 80 %: 256->512 @38x38 bs=16 (182 -> 242 tiles) +6 %, 512->1024 @13x13 bs=64
+            // (172 -> 228) +5 %, 128->256 @76x76 bs=16 (361 -> 482) +2.6 %, @76x76 bs=8 +9 % (profiles/r04aa_bf16_192row_tiles_ab.log)
+            const long long t192 = ((M + 191) / 192) * (npad / 256);
+            const long long r256 = (t256 + ncu - 1) / ncu * ncu, r192 = (t192 + ncu - 1) / ncu * ncu;
+            if (!(p.tune[1] & 16) && t192 * 100 >= 85 * r192 && t256 * 100 < 80 * r256) {
+                p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s);
+            }
             if (fill) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         }
         if (np == 1 && force == 0 && k3 && blocks256 >= (p.tune[2] > 0 ? p.tune[2] : 256) && !out_f32 && !(p.tune[1] & 8))
