@@ -33,8 +33,9 @@ def _gpu():
 # ----------------------------------------------------------------------------- decode
 @pytest.mark.parametrize("key", ["h13_s416", "h26_s416", "h52_s416", "h19_s608", "h76_s608"])
 def test_decode_vs_reference_golden(golden_dir, key):
-    """yololayer.py:31-59,97-105.  Same logits, same op order; only expf/sigmoid rounding may
-    differ (<= 2 ulp): rtol 1e-6 (fp32), plus 1e-7 abs for values near 0."""
+    """yololayer.py:31-59,97-105.  Same logits, same op order; only the rounding of exp / sigmoid may differ (csrc/yv3_common.h:
+    one v_exp_f32 with a compensated argument + one v_rcp_f32 per element, <= 4 ulp): rtol 1e-6 (fp32), plus
+    1e-7 abs for values near 0."""
     g = np.load(os.path.join(golden_dir, "decode.npz"))
     h, size, step, seed, *mask = [int(v) for v in g[key + "_cfg"]]
     logits = synth.uniform(seed, 7, 2 * 255 * h * h, -6.0, 6.0).reshape(2, 255, h, h)

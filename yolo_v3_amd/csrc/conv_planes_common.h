@@ -230,17 +230,24 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     if constexpr (SYNC) __syncthreads();              // every wave is done with the last stage
     float* tile = reinterpret_cast<float*>(lds) + wid * (GR * EP);
     float amax = 0.f;                                 // running max |v| of what this lane stores (fp16 range check)
-    // fused decode state of a head conv (OUT_F32): this lane's channel is fixed over the rows
-    const int nd = n0 + wn * WTN + lane % WTN;
+    // fused decode state of a head conv (OUT_F32): a lane owns FOUR consecutive channels (fixed over the rows) of one row per pass
+    constexpr int LPRF = OUT_F32 ? WTN / 4 : 1;       // lanes per row
+    constexpr int RPIF = 64 / LPRF;                   // rows per pass (4 for 64-channel wave tiles)
+    const int nd = n0 + wn * WTN + (lane % LPRF) * 4;
     const int attrib = p.Cout / 3;
-    const int anc = (nd >= attrib) + (nd >= 2 * attrib);
-    const int attr = nd - anc * attrib;
-    const float an = OUT_F32 ? p.dec_an[(anc < 3 ? anc : 2) * 2 + (attr == 3 ? 1 : 0)] : 0.f;
+    int dattr[4];
+    float dan[4];
     int db = 0, dgy = 0, dgx = 0;
     if constexpr (OUT_F32) {
-        // (image, grid y, grid x) of this lane's first row: two divisions once, then carried row by row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int anc = (nd + q >= attrib) + (nd + q >= 2 * attrib);
+            dattr[q] = nd + q - anc * attrib;
+            dan[q] = p.dec_an[(anc < 3 ? anc : 2) * 2 + (dattr[q] == 3 ? 1 : 0)];
+        }
+        // (image, grid y, grid x) of this lane's first row: two divisions once, then carried pass by pass
         if (p.dec_out) {
-            const int mf = m0 + wm * WTM + lane / WTN;
+            const int mf = m0 + wm * WTM + lane / LPRF;
             const int HoWo = p.Ho * p.Wo;
             db = mf / HoWo;
             const int pix = mf - db * HoWo;
@@ -275,25 +282,42 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (OUT_F32) {
-            // fp32 logits of a head conv (cout = 255: rows are 1020 bytes, nothing is 16-byte aligned): consecutive lanes
-            // take consecutive channels, so every store instruction writes one or two contiguous row segments
-            static_assert(WTN <= 64 && 64 % WTN == 0, "one or more whole rows per store instruction");
-            constexpr int RPI = 64 / WTN;
+            // fp32 rows of a head conv (cout = 255: rows are 1020 bytes, consecutive pixels are contiguous, nothing is 16-byte
+            // aligned): a lane reads four consecutive channels of a row from the LDS tile (ds_read_b128), decodes them and writes
+            // them with ONE 4-byte-aligned 16-byte store, so that a store instruction covers four whole 256-byte row segments; the
+            // lane at channel 252 writes three elements (element 255 would be the next pixel's first).
+            // Measured (tools/head_probe.py, profiles/r04ad_head_probe.txt): one element per lane and row cost 2x the plane-output
+            // epilogue before any decode arithmetic or store.
+            static_assert(WTN <= 64 && WTN % 4 == 0 && 64 % LPRF == 0, "whole rows per pass");
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
             float* yf = (float*)p.y;
-            // fused decode (yv3_decode's map, yololayer.py:31-59,97-105)
-#pragma unroll 8
-            for (int r0 = 0; r0 < GR; r0 += RPI) {
-                const int r = r0 + lane / WTN, c = lane % WTN;
-                const int m = m0 + wm * WTM + jg * GR + r, n = n0 + wn * WTN + c;
-                if (m < p.M && n < p.Cout) {
-                    const float t = tile[r * EP + c];
-                    if (yf) yf[(long long)m * p.Cout + n] = t;
-                    if (p.dec_out)
-                        p.dec_out[(long long)db * p.dec_bs + (long long)(dgy * p.Wo + dgx) * p.Cout + n] =
-                            yv3_decode_value(t, attr, an, (float)dgx, (float)dgy, p.dec_stride);
+            const int nv = p.Cout - nd;                                  // valid channels of this lane (>= 4: all)
+#pragma unroll 4
+            for (int r0 = 0; r0 < GR; r0 += RPIF) {
+                const int r = r0 + lane / LPRF;
+                const int m = m0 + wm * WTM + jg * GR + r;
+                if (m < p.M && nv > 0) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(tile + r * EP + (lane % LPRF) * 4);
+                    if (yf) {
+                        float* o = yf + (long long)m * p.Cout + nd;
+                        if (nv >= 4) *reinterpret_cast<f32x4u*>(o) = t;
+                        else { o[0] = t[0]; if (nv > 1) o[1] = t[1]; if (nv > 2) o[2] = t[2]; }
+                    }
+                    if (p.dec_out) {                                     // fused decode (yv3_decode's map, yololayer.py:31-59,97-105)
+                        f32x4 dv;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            dv[q] = (p.tune[3] & 4) ? t[q] : yv3_decode_value(t[q], dattr[q], dan[q], (float)dgx, (float)dgy, p.dec_stride);
+                        float* o = p.dec_out + (long long)db * p.dec_bs + (long long)(dgy * p.Wo + dgx) * p.Cout + nd;
+                        if (p.tune[3] & 1) asm volatile("" :: "v"(dv));   // (IO ablation for measurements: results INVALID)
+                        else if (nv >= 4) *reinterpret_cast<f32x4u*>(o) = dv;
+                        else if (nv == 3) *reinterpret_cast<f32x3u*>(o) = f32x3u{dv[0], dv[1], dv[2]};
+                        else { o[0] = dv[0]; if (nv > 1) o[1] = dv[1]; }
+                    }
                 }
-                dgx += RPI;                                             // RPI <= 2 < Wo: at most one wrap per step
-                if (dgx >= p.Wo) { dgx -= p.Wo; if (++dgy == p.Ho) { dgy = 0; ++db; } }
+                dgx += RPIF;
+                while (dgx >= p.Wo) { dgx -= p.Wo; if (++dgy == p.Ho) { dgy = 0; ++db; } }
             }
             continue;
         }

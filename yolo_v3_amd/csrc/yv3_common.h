@@ -51,12 +51,24 @@ __device__ static inline int yv3_xcd_remap(int bid, int nblk) {
 // YOLO decode of one logit (reference yololayer.py:31-59,97-105), shared by decode.hip and the fused head-conv
 // epilogue so that both produce the same bits.  attr: 0,1 = x,y; 2,3 = w,h; >= 4 = conf / class.
 //   xy : (sigmoid(t) + grid) * stride      wh : (exp(t) * (anchor / stride)) * stride      else : sigmoid(t)
+// Branch-free (a wave's lanes hold all kinds of attributes: a branch would run both sides) with ONE hardware exponential per
+// element: e^u = 2^(u*log2e), the product's rounding error and log2e's tail folded back in as a factor (1 + c*ln2), so that the
+// result stays within ~2 ulp of the correctly rounded e^u for every u (v_exp_f32 itself: 1 ulp); sigmoid = v_rcp_f32(1 + e^-t)
+// (1 ulp) -- in all <= 4 ulp from the reference's values, inside the 1e-6 relative tolerance the decode tests assert.  The library
+// exp + IEEE division this replaces were 30 % of a head conv's time (profiles/r04ad_head_probe.txt).
 #ifdef __HIPCC__
+__device__ static inline float yv3_exp(float u) {
+    const float a = u * 1.44269502e+0f;                                       // log2(e) rounded to float
+    const float c = fmaf(u, 1.92596299e-8f, fmaf(u, 1.44269502e+0f, -a));     // + its tail, + the product's rounding error
+    return __builtin_amdgcn_exp2f(a) * fmaf(c, 0.693147182f, 1.0f);           // (inf * (1 + tiny) = inf, 0 * .. = 0: no NaN)
+}
 __device__ static inline float yv3_decode_value(float t, int attr, float an, float gx, float gy, float stride) {
 #pragma clang fp contract(off)
-    if (attr == 2 || attr == 3) return (expf(t) * an) * stride;
-    const float sg = 1.f / (1.f + expf(-t));
-    if (attr >= 4) return sg;
-    return (sg + (attr == 0 ? gx : gy)) * stride;
+    const bool wh = attr == 2 || attr == 3;
+    const float e = yv3_exp(wh ? t : -t);
+    const float sg = __builtin_amdgcn_rcpf(1.f + e);
+    const float whv = (e * an) * stride;
+    const float xyv = (sg + (attr == 0 ? gx : gy)) * stride;
+    return wh ? whv : (attr >= 4 ? sg : xyv);
 }
 #endif
