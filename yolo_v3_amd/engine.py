@@ -79,6 +79,9 @@ WINO_MIN_CIN = int(os.environ.get("YV3_WINO_MIN_CIN", "256") or 256)     # Winog
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
+SK_AUTO_CELLS = int(os.environ.get("YV3_SK_AUTO_CELLS", "1536") or 1536)     # stream-K by default up to this many 32x32 cells per batch (Plan.__init__)
+
+
 WINO_MIN_CIN_F32 = 64  # exact-fp32 mode: fp32 MFMA runs at the vector rate, every 3x3 layer is matrix-bound -> from the 104x104 layers down
 
 
@@ -278,7 +281,11 @@ class Plan:
         self.flags_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flags_event = None
         # scratch of the stream-K schedule (fp16-plane kernels): zero-filled once, one per plan (= per launch stream)
-        use_sk = engine.stream_k if engine.stream_k is not None else B == 1      # automatic: single-image latency (B = 1) only
+        # automatic: small one-lane batches -- up to SK_AUTO_CELLS 32x32-pixel cells in the batch (8 images of 416 x 416), where most
+        # layers have fewer tiles than the chip has CUs and the even split over (tile, K chunk) fills them: same box, alternating
+        # (profiles/r04ag_stream_k_small_batches_ab.txt) 416x416 bs=4 +17 %, bs=8 +4 %; bs=16 -0.8 %, bs=32 -2 %, 608x608 bs=8 / 16 -4 %
+        cells = B * ((H + 31) // 32) * ((W + 31) // 32)
+        use_sk = engine.stream_k if engine.stream_k is not None else (cells <= SK_AUTO_CELLS and not two_lanes)
         self.workspace = (torch.zeros(_ffi.lib().yv3_conv_workspace_bytes(), device=dev, dtype=torch.uint8)
                           if (dt == F32H2 and use_sk) else None)
         self.layer_out = {}  # conv name -> (buffer, (h, w, c)) for bring-up / per-layer parity tests
@@ -446,8 +453,9 @@ class Engine:
         self.generation = 0
         # stream-K schedule of the 13x13 layers (+1.7 % at 416x416 bs=64): opt-in, because a tile split between two
         # workgroups is summed in a batch-position-dependent order (include/yv3.h, yv3_conv_desc.workspace)
-        # None (default): only for a single image (B = 1: every layer has a handful of tiles, splitting their K ranges over the idle
-        # CUs cuts the latency 2.25 -> 1.75 ms); True / YV3_SK=1: wherever the library's shape rule applies; False / YV3_SK=0: never
+        # None (default): small one-lane batches only (SK_AUTO_CELLS: up to 8 images of 416 x 416 -- every layer has fewer tiles than the
+        # chip has CUs, splitting their K ranges over the idle CUs cuts a single image's latency 2.25 -> 1.75 ms and gains 17 % at
+        # bs=4); True / YV3_SK=1: wherever the library's shape rule applies; False / YV3_SK=0: never
         sk = getattr(net, "stream_k", None)
         if sk is None and os.environ.get("YV3_SK") in ("0", "1"):
             sk = os.environ["YV3_SK"] == "1"
@@ -649,7 +657,7 @@ class Engine:
             plan.flags_event = None
             if flag_value & 2:
                 raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out (the stream-K schedule is automatic "
-                                    "for single images and opt-in otherwise: set net.stream_k = False or YV3_SK=0 -- or "
+                                    "for small batches and opt-in otherwise: set net.stream_k = False or YV3_SK=0 -- or "
                                     "net.deterministic = True -- to disable it, and report)")
             raise _ffi.Yv3Error(self.OVERFLOW_MSG_BF16 if self.dtype == BF16 else self.OVERFLOW_MSG)
 
