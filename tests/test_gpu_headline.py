@@ -99,6 +99,25 @@ def test_headline_plan_vs_oracle(sw1_stream, headline, lanes):
         assert tuple(a.shape) == tuple(b.shape) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,size,sk", [(4, 416, True), (9, 416, True), (10, 416, False), (4, 608, True), (5, 608, False)])
+def test_small_batch_default_plan_vs_oracle(sw1_stream, sw1_sd, headline, B, size, sk):
+    """The DEFAULT plan of small batches: up to engine.SK_AUTO_CELLS cells of 32x32 pixels (9 images of 416x416, 4 of 608x608) the
+    fp16-plane kernels run the persistent stream-K schedule (a split tile is summed head + tail: within tolerance, not bitwise, of
+    the one-tile-per-workgroup schedule) -- asserted on the plan, and every detection value of every image compared with the oracle
+    (1e-4 * max(1,|ref|)), final boxes set-wise as in test_headline_plan_vs_oracle."""
+    x = headline[0][:B] if size == 416 else torch.from_numpy(synth.images(B, size, 1000 + B))
+    net = load_sw1_net(sw1_stream).cuda()
+    det = Detector(net, B, size, size, 0.5, 0.4)
+    with torch.no_grad():
+        res = det(x.cuda())
+        ref = headline[1][:B] if size == 416 else torch.cat(oc.yolonet_forward(sw1_sd, x), 1)
+    assert det.lanes == 1 and (det.plan.workspace is not None) == sk
+    err = assert_close_rel(det.dets.cpu(), ref, TOL, "small-batch default plan B=%d %d" % (B, size))
+    d = boxes_delta(res, oc.postprocess(ref, 80, 0.5, 0.4), B)
+    print("B=%d %dx%d stream-K %s: max det err %.3g; boxes %s" % (B, size, size, sk, err, d))
+    assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["unmatched_frac"] <= 0.02, d
+
+
 @pytest.mark.parametrize("mode,n_wino", [(_ffi.F32H2, 18), (_ffi.F32, 31)])
 def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mode, n_wino):
     """``net.winograd = "always"`` (YV3_OPT_WINO_ALWAYS on every descriptor): ALL eligible layers -- 18 in the fp16-plane mode
