@@ -13,7 +13,7 @@ LAYERS = {  # name: cin, cout, k, stride, H (input), res
     "d76": (128, 256, 3, 2, 152, False), "d38": (256, 512, 3, 2, 76, False),
     "p76": (256, 128, 1, 1, 76, False), "p38": (512, 256, 1, 1, 38, False), "p19": (1024, 512, 1, 1, 19, False),
     "p52": (256, 128, 1, 1, 52, False), "p26": (512, 256, 1, 1, 26, False), "p13": (1024, 512, 1, 1, 13, False),
-    "L52": (512, 256, 3, 1, 52, True),
+    "L52": (512, 256, 3, 1, 52, True), "s104": (64, 128, 3, 2, 208, False), "s52": (128, 256, 3, 2, 104, False), "s26": (256, 512, 3, 2, 52, False), "s13": (512, 1024, 3, 2, 26, False),
 }
 B = int(os.environ.get("BB", "16"))
 iters = int(os.environ.get("ITERS", "20"))
@@ -36,8 +36,11 @@ for name in names:
         y = engine.alloc_act(B, ho, wo, cout, dt, "cuda")
         y.zero_()
         d = engine.make_desc(pc, x, y, B, H, H, r, dtype=dt)
-        d.options = (d.options & ~(0xff << 8)) | ((v % 100) << 8)
-        if v >= 200:
+        if v >= 1000:
+            d.tune[1] = v - 1000                                          # codes 1000 + t: the shipped tile selection with tune[1] = t (conv_planes.hip)
+        else:
+            d.options = (d.options & ~(0xff << 8)) | ((v % 100) << 8)
+        if 200 <= v < 1000:
             d.options |= _ffi.OPT_K3S1                                    # codes 2xx: the kw-tap-reuse kernel (conv_planes_k3s1.hip)
         descs.append(d); outs.append(y)
         for _ in range(3):
