@@ -1,4 +1,5 @@
-"""Cycle split of one persistent-stream workgroup (blockIdx 100; conv_planes.hip "PS") -- needs a -DYV3_TIMELINE build (YV3_LIB=...):
+"""Cycle split of one persistent-stream workgroup (blockIdx 100) -- needs tools/probes/conv_planes_persistent_stream.patch.txt applied
+(the experiment of profiles/r04an_persistent_stream_ab.txt; not in the shipped kernels) and a -DYV3_TIMELINE build (YV3_LIB=...):
 per wave: prologue (once) | per tile: first load segment (incl. the wait for the previous epilogue's stores), rest of the main loop, epilogue."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
