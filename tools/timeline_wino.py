@@ -18,6 +18,7 @@ for name, (cin, cout, H) in {"c13": (512, 1024, 13), "c26": (256, 512, 26)}.item
     ws = torch.zeros(lib.yv3_wino_workspace_bytes(B, H, H, cin), dtype=torch.uint8, device="cuda")
     d = engine.make_desc(pc, x, y, B, H, H, r, dtype=dt, wino_ws=ws)
     d.options |= _ffi.OPT_WINO_ALWAYS
+    d.tune[1] |= int(os.environ.get("ALT", "0"))
     for _ in range(3):
         _ffi.check(lib.yv3_conv2d(d, _ffi.stream_ptr()))
     torch.cuda.synchronize()

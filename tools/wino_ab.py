@@ -26,7 +26,7 @@ for name in sys.argv[1:] or ["c26", "c13"]:
     descs[1].options |= _ffi.OPT_WINO_ALWAYS | _ffi.OPT_WINO_EVEN
     descs[2].options |= _ffi.OPT_WINO_ALWAYS
     descs[3].options |= _ffi.OPT_WINO_ALWAYS
-    descs[3].tune[1] |= 2                      # the OTHER main loop of the GEMM stage (rolling <-> ping-pong, csrc/conv_planes.hip launch_wino)
+    descs[3].tune[1] |= int(os.environ.get("ALT", "2"))   # ALT=2: the OTHER main loop of the GEMM stage (rolling <-> ping-pong, csrc/conv_planes.hip launch_wino)
     for d in descs:
         for _ in range(3):
             _ffi.check(lib.yv3_conv2d(d, st))
