@@ -62,8 +62,8 @@ import torch.distributed as dist   # noqa: E402
 # ceiling for ALGORITHMIC fp32 FLOP/s in those modes is 2500/6 and 2500/3 (frac == utilisation of the 16-bit matrix pipe).
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "f32h2": 2500.0 / 3}
 DTYPE_NAME = {"f32": "f32 (exact fp32 MFMA)", "bf16": "bf16 (fp32 accumulate)",
-              "f32x3": "f32 via exact 3-way bf16 split: 6 bf16 MFMAs per product, fp32 accumulate",
-              "f32h2": "f32 via 2-way fp16 split (hi+lo): 3 fp16 MFMAs per product, fp32 accumulate"}
+              "f32x3": "f32x3: fp32 emulated by an exact 3-way bf16 split (6 bf16 MFMAs per product, fp32 accumulate)",
+              "f32h2": "f32h2: fp32 EMULATED by a 2-way fp16 split (22 significant bits, fp16 range; 3 fp16 MFMAs per product, fp32 accumulate)"}
 MFMAS_PER_PRODUCT = {"f32": 1, "bf16": 1, "f32x3": 6, "f32h2": 3}
 INSTR_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0, "f32h2": 2500.0}   # dense peak of the MFMA the mode issues
 KERNEL_NAME = {"f32": "conv_igemm_f32_kernel", "bf16": "conv_planes_kernel<1>", "f32x3": "conv_planes_kernel<3>",
@@ -270,6 +270,28 @@ class Workload:
                                                                          for p in self.det.lane_plans)
         return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, plan.n_desc - plan.first_desc
 
+    def algorithmic_bytes(self):
+        """ALGORITHMIC HBM bytes of the launches timed as the 'convs' stage (one lane): every conv reads its input once, its
+        residual once (second conv of a res_layer), its packed weights once and writes its output once.  Element size: 4 B in
+        f32 / f32h2 (two fp16 planes), 6 B in f32x3, 2 B in bf16; head logits are fp32 in every mode; an upsample+concat input
+        (768 / 384 channels) reads its upsampled part at the lower resolution.  DESIGN.md section 4."""
+        from yolo_v3_amd import arch
+        eb = {"f32": 4, "f32h2": 4, "f32x3": 6, "bf16": 2}[self.mode]
+        specs = arch.conv_specs()
+        hw = arch.conv_output_hw(self.size)
+        first = 1 + self.det.plan.first_desc
+        tot = 0
+        for sp, (h, w) in list(zip(specs, hw))[first:]:
+            hin, win = h * sp.stride, w * sp.stride
+            if sp.cin in (768, 384):
+                up = sp.cin // 3
+                rd = (hin // 2) * (win // 2) * up + hin * win * (sp.cin - up)
+            else:
+                rd = hin * win * sp.cin
+            out_b = h * w * sp.cout * (eb if sp.bn else 4)
+            tot += self.B * (rd * eb + out_b + (out_b if sp.res2 else 0)) + sp.cout * sp.cin * sp.k * sp.k * eb
+        return tot
+
     def executed(self):
         """EXECUTED matrix work of the launches timed as the 'convs' stage, next to the algorithmic (direct-form) count of
         `flops()`: (executed 2*MAC -- a launch that takes the Winograd F(2x2,3x3) form, as the library reports it through
@@ -463,6 +485,78 @@ def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=Non
     return True
 
 
+def _pick(d, keys, rename=None):
+    """{k: d[k]} for the keys present (numbers / short strings only), optionally renamed."""
+    rename = rename or {}
+    return {rename.get(k, k): d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac", "mfma_util", "clock_ghz",
+             "traffic", "algorithmic_bytes", "launches", "winograd_launches", "avg_launch_ms", "conv_ms_per_step")
+
+
+def compact_line(out, full_path=None):
+    """The ONE line the driver parses (contract: < 4 KB): numbers and short labels only.  Everything else -- per-mode and per-config
+    objects, the per-rank table, the PCIe-inclusive passes, every explanatory note -- is in the full object (`full`); what the fields
+    mean is DESIGN.md section 8."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_img", "higher_is_better",
+                             "scaling", "vs_baseline", "dtype", "data") if k in out}
+    c["config"] = _pick(out.get("config", {}), ("workload", "global_batch", "parallelism", "entry", "collective", "backend"))
+    if "lanes" in out:
+        c["config"]["lanes"] = out["lanes"]
+    if "ok" in out:
+        c["ok"] = out["ok"]
+    if "roofline" in out:
+        r = _pick(out["roofline"], ROOF_KEYS)
+        if "kernel" in r:
+            r["kernel"] = r["kernel"].split(" (")[0]
+        two = out["roofline"].get("two_lanes_section")
+        if two:
+            r["two_lanes"] = _pick(two, ("achieved", "frac", "executed_frac"))
+        c["roofline"] = r
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["cpu_baseline"]["sample"] = "oracle on 8 images 416x416, best of 2"
+    if "boxes_delta" in out:
+        c["boxes_delta"] = _pick(out["boxes_delta"], ("images", "ref_boxes", "got_boxes", "matched_iou_ge_0.999", "max_rel_err_coords", "tolerance"),
+                                 {"ref_boxes": "ref", "got_boxes": "got", "matched_iou_ge_0.999": "matched", "max_rel_err_coords": "max_rel_err"})
+    modes = out.get("modes", {})
+    for key, mode in (("exact_f32", "f32"), ("bf16", "bf16"), ("f32x3", "f32x3")):
+        if mode in modes:
+            m = modes[mode]
+            c[key] = dict(_pick(m, ("value", "ms_per_step")), **_pick(m.get("roofline", {}), ("frac", "executed_frac", "mfma_util", "clock_ghz")))
+    cfgs = out.get("configs", {})
+    if cfgs:
+        c["configs"] = {}
+        for k, v in cfgs.items():
+            if k == "0":
+                c["configs"][k] = _pick(v, ("gpu_ms_per_img", "boxes"))
+            else:
+                c["configs"][k] = dict(_pick(v, ("value", "ms_per_step", "lanes")), **_pick(v.get("roofline", {}), ("frac", "executed_frac")))
+    pc = out.get("pcie_inclusive", {})
+    if "double_buffered" in pc:
+        c["pcie_inclusive"] = {"serial": pc.get("serial", {}).get("images_per_sec"), "double_buffered": pc["double_buffered"]["images_per_sec"]}
+    if "ranks" in out and len(out["ranks"]) > 1:
+        c["ranks"] = [_pick(r, ("rank", "lanes", "own_ms_per_step")) for r in out["ranks"]]
+    if full_path:
+        c["full"] = full_path
+    return c
+
+
+def write_full(out, args):
+    """The full result object as a side file (gpurun_out/ is merged back from the GPU box); returns its repo-relative path."""
+    try:
+        d = os.path.join(REPO, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        name = "bench_full.json" if out.get("n_gpus", 1) == 1 else "bench_full_%dgpu.json" % out["n_gpus"]
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(out, f)
+        return "gpurun_out/" + name
+    except OSError:
+        return None
+
+
 def dry_run(args, rank, world):
     """Launcher / rendezvous / collective / JSON-line rehearsal on CPU tensors: every rank builds a synthetic payload
     with the PRODUCT's pack function, runs the product's single all-gather K times (barrier + max-over-ranks timing as
@@ -491,11 +585,11 @@ def dry_run(args, rank, world):
     res, status = ydist.assemble_global(gathered, spans, B, max_cand=cap)
     ok = status == 0 and len(res) == B * world and all((r.shape[0] if r.numel() else 0) == g % 3 for g, r in enumerate(res))
     if rank == 0:
-        print(json.dumps({"metric": "dry run: launcher + pack/gather/assemble on CPU tensors (no kernels)", "value": None, "unit": "images/sec",
+        print(json.dumps(compact_line({"metric": "dry run: launcher + pack/gather/assemble on CPU tensors (no kernels)", "value": None, "unit": "images/sec",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "n/a", "data": "dry-run",
                           "config": {"workload": "dry run", "global_batch": B * world, "parallelism": "dp%d" % world,
-                                     "backend": dist.get_backend() if world > 1 else None}, "ok": bool(ok)}))
+                                     "backend": dist.get_backend() if world > 1 else None}, "ok": bool(ok)}), separators=(",", ":")))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -520,6 +614,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic "
                     "(~1 min, N=1 only); attach the committed summary of such passes instead")
+    ap.add_argument("--full-line", action="store_true", help="also print the FULL result object (modes, configs, per-rank table, notes; "
+                    "~20 KB) as an earlier stdout line; it is always written to gpurun_out/bench_full.json")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collective rehearsal on CPU tensors (no GPU needed)")
     ap.add_argument("--weights", default="sw1", choices=["sw1", "dense", "eval"],
                     help="sw1: ~50-150 candidates/img; dense: ~1e4 rows/img pass conf (BASELINE configs[4]); eval: SW-eval")
@@ -614,6 +710,7 @@ def main():
     out = None
     if rank == 0:
         fa, fi, n_desc = roof_w.flops()
+        alg_bytes = roof_w.algorithmic_bytes()
         st = head1["stages_ms"]
         out = {
             "metric": "images/sec (YOLOv3 forward + decode + NMS, %dx%d, bs=%d per GPU)" % (args.size, args.size, B),
@@ -882,7 +979,11 @@ def main():
             "max_abs_err_conf": float("%.3g" % d["max_abs_err_conf"]), "max_abs_err_score": float("%.3g" % d["max_abs_err_score"]),
             "tolerance": 1e-4}
     if rank == 0:
-        print(json.dumps(out))
+        out["roofline"]["algorithmic_bytes"] = round(alg_bytes / n_desc)
+        full_path = write_full(out, args)
+        if args.full_line:
+            print(json.dumps(out))                                       # an EARLIER stdout line; the compact line stays the last one
+        print(json.dumps(compact_line(out, full_path), separators=(",", ":")))
     if world > 1:
         barrier(dev)
         dist.destroy_process_group()

@@ -30,7 +30,28 @@ def test_self_launch_two_ranks_dry_run():
 def test_one_rank_dry_run():
     r = _run(["--dry-run", "--steps", "2"])
     assert r.returncode == 0, r.stderr[-2000:]
-    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096                                  # the driver's parser gave up on a 22 KB line (BENCH_r04.parsed == null)
+    assert json.loads(last)["n_gpus"] == 1
+
+
+def test_final_line_is_compact_for_a_full_result_object():
+    """bench.compact_line over a FULL result object of a real run (profiles/r04zy_bench.json, 22 KB: modes, configs, PCIe passes,
+    notes): the line the driver parses stays < 4 KB, is valid JSON, keeps the contract's keys and carries no note strings."""
+    import bench
+    full = json.load(open(os.path.join(REPO, "profiles", "r04zy_bench.json")))
+    full["roofline"]["algorithmic_bytes"] = 264000000
+    line = json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json"), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "boxes_delta", "exact_f32"):
+        assert k in c, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "executed_frac", "mfma_util", "algorithmic_bytes"):
+        assert k in c["roofline"], k
+    assert set(c["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert "model" not in c["config"] and "workload" in c["config"]
+    assert not any("note" in k or k.endswith("_is") for k in c["roofline"])
 
 
 def test_too_few_gpus_is_an_error_not_a_one_rank_run():
