@@ -19,9 +19,9 @@ carries the gather); launched under torchrun it requires WORLD_SIZE == --gpus.  
 rendezvous, the product's pack -> gather -> assemble composition and the JSON line on CPU tensors (no GPU, no kernels;
 tests/test_bench_launcher.py).
 
-From ~12 images of 416x416 (8 of 608x608) the Detector runs the batch as two sub-batches on two concurrent HIP streams
+From 48 images of 416x416 (23 of 608x608) the Detector runs the batch as two sub-batches on two concurrent HIP streams
 ("lanes": same kernels and bits, each lane runs its own convolutions AND its own filter / NMS, so they fill each
-other's idle CUs; --lanes 1 disables; under N > 1 the automatic lane count is MIN-reduced over the ranks).  --batch is
+other's idle CUs; --lanes 1 disables; the automatic lane count is a function of the batch shape, the same on every rank).  --batch is
 images PER GPU (weak scaling, the default), --global-batch fixes the total (strong scaling; BASELINE configs[3] = 256
 over 8).  Rank 0 prints ONE JSON line.
 
@@ -658,13 +658,13 @@ def main():
     x = scenes(B, args.size, 1000 + lo, dev)
 
     t_setup = time.perf_counter() - t_proc                            # weights generated + loaded, scenes resident
-    # Workload construction holds this rank's FIRST collective when the lane count is automatic (MIN over the ranks): the time a
-    # rank spends before it -- and inside the constructor (packing, lane calibration) -- is reported per rank below
+    # Workload construction holds NO collective (round 5: the lane count is a function of the batch shape); the time a rank spends
+    # before and inside the constructor (packing, stream probe) is reported per rank below
     main_w = Workload(net, x, args.dtype, args.conf, args.nms, world=world, lanes=args.lanes or None)
     t_build = time.perf_counter() - t_proc - t_setup
     elapsed = main_w.run(args.steps, args.warmup)
     cand4, kept4 = main_w.finish(rank)
-    rank_info = {"rank": rank, "device": str(dev), "lanes": main_w.det.lanes, "lane_calibration_ms": main_w.det.lane_calibration,
+    rank_info = {"rank": rank, "device": str(dev), "lanes": main_w.det.lanes,
                  "setup_s": round(t_setup, 2), "detector_build_s": round(t_build, 2),
                  "own_ms_per_step": round(main_w.own_elapsed / args.steps * 1e3, 4)}
     ranks = [rank_info]
@@ -737,7 +737,6 @@ def main():
                                                 "mean what they say; the timed step above runs %d concurrent lanes" % (head1["value"], head1["ms_per_step"], lanes_used))
             out["roofline"]["two_lanes_section"] = {k: head["roofline"][k] for k in ("kernel", "achieved", "frac", "launches", "winograd_launches",
                                                                                   "executed_tflops", "executed_frac")}
-            out["lanes_calibration_ms"] = getattr(main_w.det, "lane_calibration", None)
         if args.no_live_traffic or world > 1 or not live_traffic(out["roofline"], args, B):
             attach_traffic(out["roofline"], args.dtype, args.size, B, n_desc)
         if args.dtype in ("f32x3", "f32h2"):
@@ -750,8 +749,8 @@ def main():
         if cfg3 is not None:
             out.setdefault("configs", {})["3"] = cfg3
         out["ranks"] = ranks
-        out["ranks_note"] = ("per rank: lanes the Detector runs (MIN-reduced over the ranks when automatic), its own lane calibration, seconds "
-                             "before / inside the Detector constructor (which holds the first collective), and its OWN clock over the timed "
+        out["ranks_note"] = ("per rank: lanes the Detector runs (a function of the batch shape + a yes/no stream-concurrency probe; no collective "
+                             "in the constructor), seconds before / inside the Detector constructor, and its OWN clock over the timed "
                              "steps (ms_per_step above is the MAX over ranks)")
     del roof_w
 

@@ -169,7 +169,9 @@ typedef struct yv3_conv_desc {
     unsigned  options;                /* OR of YV3_OPT_*                                          */
     int       big_tile_min;           /* plane kernels: minimum number of 256x128 tiles for which that tile is
                                          used instead of 128x128 (0: default 128 = half a round of the chip) */
-    int       tune[4];                /* kernel-tuning experiments (0 = off); meaning private to the kernels */
+    int       tune[4];                /* kernel-SELECTION experiments (0 = off; tune[0..2]: every setting gives valid results of the same
+                                         arithmetic).  tune[3] is IGNORED by the shipped libyv3.so: the IO ablations it selects
+                                         (invalid results) exist only in measurement builds compiled with -DYV3_MEASURE */
     /* Plane strides in ELEMENTS for plane dtypes, 0 = the packed default B*H*W*C of that tensor.  They let one launch work
        on a batch SLICE of [NP][B_total,H,W,C] tensors (x / x2 / y + residual: base pointers offset by b0*H*W*C, B = slice
        size, strides = those of the full tensors): the engine runs a layer whose tiles fill between one and two rounds of the

@@ -92,6 +92,9 @@ def state_dict_from_stream(stream, num_class=80):
 #           fp32 decode and post-processing.  A bf16 x bf16 product is exact in fp32, so the only difference
 #           between two implementations of this definition is the fp32 summation order.  Pinned by running the
 #           reference's own modules with rounding hooks (oracle/make_golden_bf16.py -> tests/golden/e2e_bf16.npz).
+#   "bf16-halves"  the same definition evaluated in ANOTHER fp32 summation order (each conv as the sum of two convs over
+#           the two halves of its input channels): tests use the spread between the two CPU evaluations as the yardstick
+#           for what any implementation of the definition can be held to end to end.
 def round_bf16(t):
     """fp32 -> nearest bfloat16 (ties to even) -> fp32."""
     return t.bfloat16().float()
@@ -100,13 +103,19 @@ def round_bf16(t):
 def cbr(sd, prefix, x, stride=1, prec=None, store=True):
     """reference darknet.py:27-44: conv(no bias, pad=(k-1)//2) -> BatchNorm2d(eval) -> LeakyReLU(0.1)."""
     w = sd[prefix + ".conv.weight"]
-    if prec == "bf16" and w.shape[1] != 3:
+    bf = prec in ("bf16", "bf16-halves")
+    if bf and w.shape[1] != 3:
         w = round_bf16(w)
-    y = F.conv2d(x, w, None, stride, (w.shape[2] - 1) // 2)
+    pad = (w.shape[2] - 1) // 2
+    if prec == "bf16-halves" and w.shape[1] >= 2:
+        h = w.shape[1] // 2
+        y = F.conv2d(x[:, :h], w[:, :h], None, stride, pad) + F.conv2d(x[:, h:], w[:, h:], None, stride, pad)
+    else:
+        y = F.conv2d(x, w, None, stride, pad)
     y = F.batch_norm(y, sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"],
                      sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], False, 0.1, 1e-5)
     y = F.leaky_relu(y, 0.1)
-    return round_bf16(y) if (prec == "bf16" and store) else y
+    return round_bf16(y) if (bf and store) else y
 
 
 def backbone(sd, x, taps=None, prec=None):
@@ -123,7 +132,7 @@ def backbone(sd, x, taps=None, prec=None):
             h = cbr(sd, p + ".conv1", x, prec=prec)
             if taps is not None: taps.append((p + ".conv1", h))
             x = x + cbr(sd, p + ".conv2", h, prec=prec, store=False)   # darknet.py:53 (the sum is what is stored)
-            if prec == "bf16":
+            if prec in ("bf16", "bf16-halves"):
                 x = round_bf16(x)
             if taps is not None: taps.append((p + ".conv2", x))
             idx += 1
@@ -141,7 +150,7 @@ def predet(sd, prefix, x, taps=None, prec=None):
         if i == 4:
             route = x                                               # darknet.py:185 addCachedOut(-3)
     w = sd[prefix + ".mlist.6.weight"]
-    logits = F.conv2d(x, round_bf16(w) if prec == "bf16" else w, sd[prefix + ".mlist.6.bias"])   # fp32 logits
+    logits = F.conv2d(x, round_bf16(w) if prec in ("bf16", "bf16-halves") else w, sd[prefix + ".mlist.6.bias"])   # fp32 logits
     if taps is not None: taps.append((prefix + ".mlist.6", logits))
     return logits, route
 

@@ -75,9 +75,10 @@ def _worker(rank, world, port, q):
     for r_ in range(world):
         want_status |= r_
     ok = ok and res0 == [] and status0 == want_status
-    # rank-consistent lane count: MIN over the ranks of each rank's own calibration decision
-    from yolo_v3_amd.detect import _min_over_group
-    ok = ok and _min_over_group(2 if rank != world - 1 else 1, None, "cpu") == 1 and _min_over_group(2, None, "cpu") == 2
+    # rank-consistent lane count WITHOUT a collective: the automatic choice is a pure function of the batch shape
+    import importlib
+    ydet = importlib.import_module("yolo_v3_amd.detect")           # (the package exports the FUNCTION detect under that name)
+    ok = ok and ydet.TWO_LANES_MIN_PIXELS == 48 * 416 * 416 and not hasattr(ydet, "_min_over_group")
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -91,7 +92,7 @@ def test_gather_boxes_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=60) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

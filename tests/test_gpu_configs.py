@@ -41,7 +41,7 @@ def test_config2_all_32_images_vs_oracle(net, sw1_sd, mode):
     """416x416 bs=32, SW-1, conf 0.5 / nms 0.4: ALL 32 images against the oracle (not a property check).
     Detections within 1e-4 * max(1,|ref|) everywhere.  Boxes are compared set-wise (oracle/boxdelta.py): random
     scenes are not margin-selected, so a decision may sit inside fp32 noise of a threshold; matched boxes must
-    agree to 1e-4 and at most 1 % of the boxes may be unmatched (measured: see the printed delta)."""
+    agree to 1e-4 and at most 0.2 % of the boxes may be unmatched (measured in rounds 3-4: 0 of 2567 in every mode)."""
     net.math_mode = mode
     x = torch.from_numpy(synth.images(32, 416, 1))
     with torch.no_grad():
@@ -54,7 +54,8 @@ def test_config2_all_32_images_vs_oracle(net, sw1_sd, mode):
     print("config2 mode %d: max det err %.3g; boxes %s" % (mode, err, d))
     assert d["ref_boxes"] > 300
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["max_abs_err_score"] <= TOL
-    assert d["unmatched_frac"] <= 0.01, d
+    print("config2 mode %d: unmatched_frac %.5f (bound 0.002)" % (mode, d["unmatched_frac"]))
+    assert d["unmatched_frac"] <= 0.002, d
     net.math_mode = _ffi.F32H2
 
 
@@ -101,7 +102,10 @@ def test_config3_full_size_vs_bf16_oracle():
     everything downstream, and two CPU evaluations of the SAME bf16 definition that differ only in summation order
     (F.conv2d over all input channels vs over two halves) already differ by mean 1.3e-3 / max 6.7e-2 in
     |d|/max(1,|ref|) on these inputs -- as much as bf16 differs from fp32 (1.4e-3 / 8e-2).  Tolerance = that
-    measured spread with margin: mean <= 4e-3, 99.9th percentile <= 6e-2.  Boxes set-wise at IOU >= 0.5."""
+    measured spread with margin: mean <= 4e-3, 99.9th percentile <= 6e-2.  Boxes set-wise at IOU >= 0.5, and the bound on the
+    unmatched fraction is DERIVED HERE: the oracle is evaluated a second time in the other summation order
+    (``prec="bf16-halves"``), its box set compared with the first evaluation's the same way, and the HIP path may leave at
+    most 1.5x that CPU-vs-CPU fraction unmatched (measured: CPU-vs-CPU 0.069, HIP-vs-CPU 0.074)."""
     assert torch.cuda.is_available()
     torch.cuda.set_device(0)
     stream = synth.weight_stream()
@@ -120,8 +124,17 @@ def test_config3_full_size_vs_bf16_oracle():
     want = oc.postprocess(ref, 80, 0.5, 0.4)
     res = postprocessing(got, 80, 0.5, 0.4)
     d = boxes_delta(res, want, 16, iou_match=0.5)
+    with torch.no_grad():
+        ref2 = torch.cat(oc.yolonet_forward(sd, x, prec="bf16-halves"), 1)
+    e2 = rel_err(ref2, ref)
+    d_cpu = boxes_delta(oc.postprocess(ref2, 80, 0.5, 0.4), want, 16, iou_match=0.5)
+    bound = 1.5 * d_cpu["unmatched_frac"]
     print("config3 boxes (IOU >= 0.5 pairs):", d)
-    assert d["ref_boxes"] > 100 and d["unmatched_frac"] <= 0.35, d
+    print("config3: two CPU evaluations of the bf16 oracle (summation order only): detections mean %.3g, boxes unmatched_frac %.4f"
+          " -> bound %.4f; HIP vs oracle unmatched_frac %.4f" % (float(e2.mean()), d_cpu["unmatched_frac"], bound, d["unmatched_frac"]))
+    assert d_cpu["ref_boxes"] > 100 and 0.0 < d_cpu["unmatched_frac"] < 0.2
+    assert float(e.mean()) <= 1.5 * float(e2.mean())
+    assert d["ref_boxes"] > 100 and d["unmatched_frac"] <= bound, d
 
 
 # ----------------------------------------------------------------------------- configs[4]
@@ -129,7 +142,7 @@ def test_config5_dense_full_network_vs_oracle():
     """608x608 bs=8 with SW-dense (head biases +1/+1: ~1e4 rows per image pass conf 0.5, thousands in one class),
     the WHOLE network + post-processing against the oracle, compared set-wise as SURVEY 8(d) prescribes (class +
     IOU >= 0.999; decisions inside fp32 noise of a threshold may flip, and a flipped suppressor changes the fate of
-    the boxes it would have suppressed).  Asserted: detections within 1e-4, unmatched fraction <= 2 %, matched boxes
+    the boxes it would have suppressed).  Asserted: detections within 1e-4, unmatched fraction <= 1 % (measured: 0), matched boxes
     within 1e-4; and on IDENTICAL detections (the GPU's own) the post-processing equals the oracle's bit for bit."""
     assert torch.cuda.is_available()
     torch.cuda.set_device(0)
@@ -152,7 +165,8 @@ def test_config5_dense_full_network_vs_oracle():
     print("config5: candidates/img %s; boxes %s" % (ncand.tolist(), d))
     assert d["ref_boxes"] > 8 * 2000
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_score"] <= TOL
-    assert d["unmatched_frac"] <= 0.02, d
+    print("config5: unmatched_frac %.5f (bound 0.01)" % d["unmatched_frac"])
+    assert d["unmatched_frac"] <= 0.01, d
 
 
 # ----------------------------------------------------------------------------- default mode on hostile data
@@ -351,7 +365,7 @@ def test_eval_mode_at_reference_thresholds(golden_dir):
     """evaluate.py:201-204: obj_conf_thr 0.005, nms_thr 0.45, is_eval=True -- the values the reference's
     predict_and_process hard-codes -- with the SW-eval weights (1-2 k (row, class) candidates per image).
     (a) decisions on IDENTICAL detections equal the oracle's bit for bit; (b) against the REFERENCE's own boxes
-    (tests/golden/e2e_eval.npz) set-wise: matched boxes within 1e-4, <= 1 % unmatched; (c) predict_and_process with
+    (tests/golden/e2e_eval.npz) set-wise: matched boxes within 1e-4, <= 0.2 % unmatched; (c) predict_and_process with
     its default thresholds hands exactly those boxes to the batch handler."""
     import os
     from yolo_v3_amd import evaluate
@@ -370,7 +384,7 @@ def test_eval_mode_at_reference_thresholds(golden_dir):
     want = [torch.from_numpy(g["boxes%d" % i]) for i in range(B)]
     d = boxes_delta(res, want, B)
     print("eval mode 0.005/0.45 vs reference:", d)
-    assert d["ref_boxes"] > 1000 and d["unmatched_frac"] <= 0.01
+    assert d["ref_boxes"] > 1000 and d["unmatched_frac"] <= 0.002          # (measured: 0 of 1132)
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_score"] <= TOL
 
     class Rec(evaluate.BatchHandler):

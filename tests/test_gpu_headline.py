@@ -65,10 +65,10 @@ def _form_counts(plan):
 def test_headline_plan_vs_oracle(sw1_stream, headline, lanes):
     """bench.py's timed step, as bench.py builds it (`Workload`: ``Detector(net, 64, 416, 416, 0.5, 0.4, lanes=None)``), on
     bench.py's 64 scenes: every detection value of all 64 images within 1e-4 * max(1,|ref|) of the oracle, final boxes
-    set-wise (class + IOU >= 0.999; random scenes are not margin-selected) with matched boxes within 1e-4 and <= 1 %
-    unmatched.  The plan is asserted, not assumed: with two lanes of 32 images every 256->512 @26x26 and 512->1024 @13x13
+    set-wise (class + IOU >= 0.999; random scenes are not margin-selected) with matched boxes within 1e-4 and <= 0.2 %
+    unmatched (measured in rounds 3-4: 0 of 5102).  The plan is asserted, not assumed: with two lanes of 32 images every 256->512 @26x26 and 512->1024 @13x13
     layer (18 launches per lane) must take the Winograd form; with one lane of 64 the seven 13x13 layers.  lanes=None is
-    the automatic choice the benchmark runs (two lanes wherever the calibration finds a concurrent stream pair)."""
+    the automatic choice the benchmark runs (two lanes at this batch size wherever a concurrent stream pair exists)."""
     x, ref, want = headline
     net = load_sw1_net(sw1_stream).cuda()
     det = Detector(net, 64, 416, 416, 0.5, 0.4, lanes=lanes)
@@ -91,7 +91,8 @@ def test_headline_plan_vs_oracle(sw1_stream, headline, lanes):
           % (lanes, det.lanes, [sum(v[1] for v in fc.values()) for fc in forms], err, d))
     assert d["ref_boxes"] > 600
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["max_abs_err_score"] <= TOL
-    assert d["unmatched_frac"] <= 0.01, d
+    print("headline lanes=%s: unmatched_frac %.5f (bound 0.002)" % (lanes, d["unmatched_frac"]))
+    assert d["unmatched_frac"] <= 0.002, d
     # decisions on IDENTICAL detections (the detector's own) are the oracle's, bit for bit
     exact = oc.postprocess(det.dets.cpu(), 80, 0.5, 0.4)
     assert len(res) == len(exact)
@@ -115,7 +116,8 @@ def test_small_batch_default_plan_vs_oracle(sw1_stream, sw1_sd, headline, B, siz
     err = assert_close_rel(det.dets.cpu(), ref, TOL, "small-batch default plan B=%d %d" % (B, size))
     d = boxes_delta(res, oc.postprocess(ref, 80, 0.5, 0.4), B)
     print("B=%d %dx%d stream-K %s: max det err %.3g; boxes %s" % (B, size, size, sk, err, d))
-    assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["unmatched_frac"] <= 0.02, d
+    print("B=%d %d: unmatched_frac %.5f (bound 0.005)" % (B, size, d["unmatched_frac"]))
+    assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["unmatched_frac"] <= 0.005, d
 
 
 @pytest.mark.parametrize("mode,n_wino", [(_ffi.F32H2, 18), (_ffi.F32, 31)])
@@ -140,7 +142,8 @@ def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mod
     res = detect(net, x.cuda(), 80, 0.5, 0.4)
     d = boxes_delta(res, want, 32)
     print("forced Winograd mode %d: %d Winograd launches, max det err %.3g; boxes %s" % (mode, n_wino, err, d))
-    assert d["ref_boxes"] > 300 and d["unmatched_frac"] <= 0.01, d
+    print("forced Winograd mode %d: unmatched_frac %.5f (bound 0.002)" % (mode, d["unmatched_frac"]))
+    assert d["ref_boxes"] > 300 and d["unmatched_frac"] <= 0.002, d
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["max_abs_err_score"] <= TOL
     # the reference's own output for the dog image (tests/golden/e2e.npz)
     g = np.load(os.path.join(golden_dir, "e2e.npz"))
@@ -192,4 +195,61 @@ def test_config4_full_size_8_ranks_equals_single_gpu():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     print("config 4, 8 ranks on one GPU:", out)
     assert out["world"] == 8 and out["images"] == 256 and out["shard"] == 32 and out["collectives_per_call"] == 1
-    assert out["bitwise_equal_images"] == 256 and out["boxes"] > 2000 and out["default_mode_unmatched_frac"] <= 0.01
+    assert out["bitwise_equal_images"] == 256 and out["boxes"] > 2000 and out["default_mode_unmatched_frac"] <= 0.002
+
+
+def test_form_query_mirrors_the_launch_dispatch(sw1_stream, monkeypatch):
+    """yv3_conv2d_form must report what yv3_conv2d does.  (a) with the opt-in kw-tap-reuse kernel (YV3_OPT_K3S1, set
+    through the measurement environment) the 3x3 stride-1 layers are dispatched to it BEFORE the Winograd rule: form = direct even
+    under ``net.winograd = "always"``; (b) a shape the launch rejects (cout not a multiple of 8 for a plane output; a Winograd
+    workspace that is too small) gives the same negative code from the query and from the launch."""
+    import ctypes
+    monkeypatch.setenv("YV3_MEASURE", "1")
+    monkeypatch.setenv("YV3_K3S1", "1")
+    net = load_sw1_net(sw1_stream).cuda()
+    net.winograd = "always"
+    plan = net.engine().plan(4, 416, 416)
+    assert sum(f for _, f in plan.forms()) == 0
+    monkeypatch.delenv("YV3_K3S1")
+    net2 = load_sw1_net(sw1_stream).cuda()
+    net2.winograd = "always"
+    plan2 = net2.engine().plan(4, 416, 416)
+    forms = plan2.forms()
+    assert sum(f for _, f in forms) == 18
+    lib = _ffi.lib()
+    j = plan2.first_desc + [f for _, f in forms].index(1)
+    d = type(plan2.descs[j])()
+    ctypes.memmove(ctypes.byref(d), ctypes.byref(plan2.descs[j]), ctypes.sizeof(d))
+    d.wino_ws_bytes = 16
+    assert lib.yv3_conv2d_form(ctypes.byref(d)) == -3 == lib.yv3_conv2d(ctypes.byref(d), _ffi.stream_ptr())     # YV3_EWORKSPACE
+    ctypes.memmove(ctypes.byref(d), ctypes.byref(plan2.descs[j]), ctypes.sizeof(d))
+    d.cout = d.cout - 4
+    assert lib.yv3_conv2d_form(ctypes.byref(d)) == -2 == lib.yv3_conv2d(ctypes.byref(d), _ffi.stream_ptr())     # YV3_ESHAPE
+    torch.cuda.synchronize()
+
+
+def test_stray_tuning_environment_does_not_change_results(sw1_stream, monkeypatch):
+    """with YV3_TUNE=0,0,0,7 (the IO ablations: no stores, no residual loads, no decode) and friends in the
+    environment -- but no YV3_MEASURE=1 -- detect() returns the same bits as without them: the host side does not read them and
+    the shipped library has the branches compiled out."""
+    x = torch.from_numpy(synth.images(4, 416, 77)).cuda()
+    net = load_sw1_net(sw1_stream).cuda()
+    with torch.no_grad():
+        want = detect(net, x, 80, 0.5, 0.4)
+        dets = net.forward_cat(x).clone()
+    monkeypatch.delenv("YV3_MEASURE", raising=False)
+    for k, v in (("YV3_TUNE", "0,0,0,7"), ("YV3_TILE", "3"), ("YV3_NO_PP", "1"), ("YV3_WINO_ALWAYS", "1"), ("YV3_NO_FUSED_DECODE", "1")):
+        monkeypatch.setenv(k, v)
+    net2 = load_sw1_net(sw1_stream).cuda()
+    with torch.no_grad():
+        got = detect(net2, x, 80, 0.5, 0.4)
+        dets2 = net2.forward_cat(x)
+    assert torch.equal(dets, dets2)
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    # ... and even a descriptor that carries tune[3] = 7 runs the full epilogue in the shipped library
+    plan = net2.engine().plan(4, 416, 416)
+    for j in range(plan.n_desc):
+        plan.descs[j].tune[3] = 7
+    with torch.no_grad():
+        dets3 = net2.forward_cat(x)
+    assert torch.equal(dets, dets3)

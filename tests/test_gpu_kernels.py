@@ -63,6 +63,23 @@ def test_decode_non_square_and_small_classes():
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
 
 
+def test_decode_non_finite_and_huge_logits_like_the_reference():
+    """exp(+inf) = inf, sigmoid(+inf) = 1, sigmoid(-inf) = 0, and the same for |t| ~ 1e38 / 3e38 (where t * log2(e)
+    overflows); NaN logits stay NaN -- exactly what the reference's torch.exp / torch.sigmoid return (oracle)."""
+    vals = [float("inf"), float("-inf"), 1e38, -1e38, 3e38, -3e38, 89.0, -104.0, 100.0, -110.0, float("nan"), 0.0]
+    x = torch.zeros(1, 3 * 9, 4, 3)
+    x.view(-1)[:len(vals) * 27:27] = torch.tensor(vals)              # spread over positions ...
+    for c in range(27):                                              # ... and put every value into every attribute kind
+        x[0, c, c % 4, c % 3] = vals[c % len(vals)]
+    ref = oc.decode(x, [a for p in ANCHOR_PAIRS for a in p], (3, 4, 5), (96, 128), num_class=4)
+    out = YoloLayer(ANCHOR_PAIRS, [3, 4, 5], (96, 128), 4)(x.cuda(), (96, 128)).cpu()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref))
+    assert torch.equal(torch.isinf(out), torch.isinf(ref))
+    fin = torch.isfinite(ref)
+    np.testing.assert_allclose(out[fin].numpy(), ref[fin].numpy(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(out[torch.isinf(ref)], ref[torch.isinf(ref)])
+
+
 # ----------------------------------------------------------------------------- geometry
 def test_iou_and_box_conversion_bit_exact(golden_dir):
     """utils.py:98-146, boundingbox.py:25-29: plain IEEE fp32 ops -> bitwise equal to the reference."""
@@ -498,6 +515,7 @@ def test_conv_k3s1_tap_reuse_kernel(cin, cout, B, H, W, monkeypatch):
     ref = _ref_cbr(m, x) + res.double()
     m = m.cuda()
     generic = _run_mode(m, x, _ffi.F32X3, res)
+    monkeypatch.setenv("YV3_MEASURE", "1")                  # tuning overrides are honoured in measurement sessions only
     monkeypatch.setenv("YV3_K3S1", "1")
     reuse = _run_mode(m, x, _ffi.F32X3, res)
     assert_close_rel(reuse, ref, 2e-5, "k3s1 conv")

@@ -290,8 +290,37 @@ def test_engine_reresolves_a_replaced_submodule():
     new_w = net.pre_det1.mlist[6].weight
     assert any(t is new_w for t in after) and not any(t is old.weight for t in after)
     assert eng._signature() != tuple((t.data_ptr(), t._version) for t in before)
+    # a replaced ANCESTOR -- the ModuleList, then the whole branch container -- must be seen too
+    from yolo_v3_amd.darknet import PreDetectionConvGroup
+    old_list_w = net.pre_det2.mlist[0].conv.weight
+    import copy
+    net.pre_det2.mlist = copy.deepcopy(net.pre_det2.mlist)
+    t2 = eng._param_tensors()
+    assert any(t is net.pre_det2.mlist[0].conv.weight for t in t2) and not any(t is old_list_w for t in t2)
+    old_branch_w = net.pre_det3.mlist[6].weight
+    net.pre_det3 = copy.deepcopy(net.pre_det3)
+    t3 = eng._param_tensors()
+    assert any(t is net.pre_det3.mlist[6].weight for t in t3) and not any(t is old_branch_w for t in t3)
     eng.invalidate()
     assert "_mod_slots" not in eng.__dict__
+
+
+def test_tuning_environment_is_ignored_outside_measurement_sessions(monkeypatch):
+    """a stray YV3_TUNE / YV3_TILE / ... in the environment must not reach a descriptor.  The overrides are read
+    only when YV3_MEASURE=1 (tools/gpu.sh sets it); the shipped library additionally ignores tune[3] (compiled out)."""
+    from yolo_v3_amd import engine
+    for k, v in (("YV3_TUNE", "1,2,3,7"), ("YV3_TILE", "3"), ("YV3_NO_PP", "1"), ("YV3_K3S1", "1"), ("YV3_BIG_MIN", "7"), ("YV3_SK", "1")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("YV3_MEASURE", raising=False)
+    assert engine.tuning_options() == (0, 0)
+    assert engine.measure_env("YV3_TUNE", "") == "" and engine.measure_env("YV3_SK") is None
+    monkeypatch.setenv("YV3_MEASURE", "1")
+    opts, big = engine.tuning_options()
+    assert opts & _ffi.OPT_NO_PINGPONG and opts & _ffi.OPT_K3S1 and (opts >> 8) & 0xff == 3 and big == 7
+    assert engine.measure_env("YV3_TUNE", "") == "1,2,3,7"
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yolo_v3_amd", "csrc", "conv_planes_common.h")).read()
+    body = src.split("#endif", 1)[1] if "YV3_IO_ABL" in src else src
+    assert "tune[3]" not in body                                  # only inside the #ifdef YV3_MEASURE definition of YV3_IO_ABL
 
 
 def test_gather_boxes_rejects_bad_arguments_without_touching_rccl():

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("YV3_LIB") or os.path.join(_HERE, "libyv3.so")     # YV3_LIB: kernel-tuning builds only
+# YV3_LIB (another build of the library: A/B variants, the -DYV3_MEASURE build) is honoured in measurement sessions only (YV3_MEASURE=1)
+LIB_PATH = (os.environ.get("YV3_LIB") if os.environ.get("YV3_MEASURE") == "1" else None) or os.path.join(_HERE, "libyv3.so")
 
 F32, BF16, F32X3, F32H2 = 0, 1, 2, 3
 ACT_LINEAR, ACT_LEAKY = 0, 1

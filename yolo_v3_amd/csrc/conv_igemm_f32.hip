@@ -389,6 +389,11 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
 // Does this fp32 descriptor take the Winograd F(2x2,3x3) form?  (exported through yv3_conv2d_form)
 int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
+    {   // the shape error yv3_conv2d_f32 reports before it launches anything (the form query returns what the launch would)
+        const int pad = (d->k - 1) / 2;
+        const long long Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
+        if ((long long)d->B * Ho * Wo > 0x7fffffffLL) return YV3_ESHAPE;
+    }
     if (!(d->w_wino && d->alpha_wino && k3 && d->stride == 1 && !dual && d->cout % 128 == 0 && d->cout_pad == d->cout)) return 0;
     // fp32 MFMA runs at the vector rate, so this layer is matrix-bound whatever its shape: Winograd whenever the 128x128 tiles
     // (a quarter of the direct kernel's rows) still fill a good part of the chip, or YV3_OPT_WINO_ALWAYS

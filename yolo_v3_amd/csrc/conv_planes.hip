@@ -35,11 +35,17 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { __builtin_amdg
 #ifndef YV3_PP_GRP
 #define YV3_PP_GRP(wid) ((wid) >> 2)
 #endif
+// Every compile-time measurement switch below (timeline dumps that overwrite alpha[], ablations with INVALID results, schedule
+// experiments) exists only in measurement builds: the shipped libyv3.so is compiled without any of them.
+#if !defined(YV3_MEASURE) && (defined(YV3_TIMELINE) || defined(YV3_ABLATE) || defined(YV3_WABL) || defined(YV3_PPX) || defined(YV3_PRIO) || \
+                              defined(YV3_EXP_BF16MFMA) || defined(YV3_AB_NO_TWO_LANES_RULE))
+#error "measurement switches need -DYV3_MEASURE (make measure / tools/build_variant.sh); the shipped library has none"
+#endif
 // Measurement switches.  Run time (yv3_conv_desc.tune[], set by tools/ through YV3_TUNE=a,b,c,d; 0 = the shipped behaviour):
 //   tune[1] bit 0  no two-workgroup tile for the short-K 1x1 layers      bit 1  Winograd stage: rolling instead of ping-pong main loop      bit 4  bf16: no 192-row variant of the 256x256 tile
 //           bit 3  bf16: round-3 tile selection (no rolling loop, no 256x256 tile)
 //   tune[2]        bf16: threshold (256x128 tiles) from which the four-wave tile is used
-//   tune[3] bit 0  epilogue without its stores   bit 1  without its residual loads   (results INVALID: IO ablation)
+//   tune[3] (measurement builds, -DYV3_MEASURE, only) bit 0  epilogue without its stores   bit 1  without its residual loads   (results INVALID)
 // Compile time (A/B builds through tools/build_variant.sh):
 // YV3_WABL (timing ablations of the Winograd GEMM stage's ping-pong loop, results INVALID; tools/timeline_wino.py):
 //   1 no DMA pieces in the compute segment   2 both k-steps' fragments read in the load segment (no SPLIT)
@@ -944,9 +950,45 @@ static int launch_wino(const yv3_conv_desc* d, ConvParamsP p, hipStream_t s) {
 
 extern "C" size_t yv3_conv_workspace_bytes(void) { return (size_t)YV3_SK_MAX_WG * (YV3_SK_PART_BYTES + sizeof(int)); }
 
-// Does this descriptor take the Winograd F(2x2,3x3) form?  (The per-launch rule of the fp16-plane mode; also exported through
-// yv3_conv2d_form so that callers -- tests, bench.py's executed-FLOP accounting -- see the choice the library makes.)
+static int planes_wino_rule(const yv3_conv_desc* d, int np);
+
+// The shape errors yv3_conv2d_planes reports before it launches anything: ONE function, called by the launch path and by the
+// form query, so that yv3_conv2d_form returns exactly "the YV3_E* code yv3_conv2d would return" (include/yv3.h).
+static int planes_shape_rc(const yv3_conv_desc* d) {
+    if (d->dec_out && (d->out_dtype != YV3_F32 || d->cout % 3 || d->dec_stride <= 0.f)) return YV3_ESHAPE;
+    const int pad = (d->k - 1) / 2;
+    const long long Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
+    if ((long long)d->B * Ho * Wo > 0x7fffffffLL) return YV3_ESHAPE;
+    if (d->out_dtype != YV3_F32 && (d->cout % 8)) return YV3_ESHAPE;
+    const int npad = d->cout_pad, tb = npad < 128 ? npad : 128;
+    if (tb <= 0 || npad % tb) return YV3_ESHAPE;
+    if (d->out_dtype == YV3_F32 && (d->k == 3 || d->cin_up > 0)) return YV3_ESHAPE;      // fp32 outputs are the 1x1 head convs
+    return 0;
+}
+
+// Does the opt-in kw-tap-reuse kernel (YV3_OPT_K3S1, conv_planes_k3s1.hip) take this launch?  It is dispatched BEFORE the Winograd rule.
+static bool k3s1_takes(const yv3_conv_desc* d) {
+    return d->k == 3 && d->stride == 1 && d->out_dtype != YV3_F32 && (d->options & YV3_OPT_K3S1) && d->cin % PBK == 0 &&
+           (d->cout_pad % 128 == 0 || d->cout_pad % 64 == 0);
+}
+
+// Which form does this descriptor take?  (The per-launch rule of the fp16-plane mode; also exported through yv3_conv2d_form so
+// that callers -- tests, bench.py's executed-FLOP accounting -- see the choice the library makes.)  Mirrors yv3_conv2d_planes'
+// dispatch order: shape errors, the opt-in k3s1 kernel (direct form), the Winograd rule (+ launch_wino's own errors).
 int yv3_conv2d_planes_form(const yv3_conv_desc* d, int np) {
+    const int src = planes_shape_rc(d);
+    if (src) return src;
+    if (k3s1_takes(d)) return YV3_FORM_DIRECT;
+    const int w = planes_wino_rule(d, np);
+    if (w == 1) {
+        const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+        if (T > 0x7fffffffLL || d->cout_pad % 128 || d->cin % 32) return YV3_ESHAPE;
+        if (!d->wino_ws || d->wino_ws_bytes < (size_t)2 * 16 * T * d->cin * sizeof(u16)) return YV3_EWORKSPACE;
+    }
+    return w;
+}
+
+static int planes_wino_rule(const yv3_conv_desc* d, int np) {
     const int npad = d->cout_pad;
     const bool k3 = d->k == 3, dual = d->cin_up > 0, out_f32 = d->out_dtype == YV3_F32;
     if (!(d->w_wino && np == 2 && k3 && d->stride == 1 && !out_f32 && !dual && d->alpha_wino && npad % 128 == 0 &&
@@ -973,6 +1015,8 @@ int yv3_conv2d_planes_form(const yv3_conv_desc* d, int np) {
 }
 
 int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
+    const int src = planes_shape_rc(d);
+    if (src) return src;
     ConvParamsP p;
     p.x = (const u16*)d->x; p.x2 = (const u16*)d->x2; p.w = (const u16*)d->w;
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const u16*)d->residual; p.y = d->y;
@@ -1014,11 +1058,11 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
     // kw-tap reuse kernel (conv_planes_k3s1.hip): 44 % less L2->LDS traffic, same results, but no faster on
     // MI355X because this MFMA stream is power-limited -- opt-in until that changes.
-    if (k3 && d->stride == 1 && !out_f32 && (d->options & YV3_OPT_K3S1)) {
+    if (k3s1_takes(d)) {
         const int rc = yv3_conv2d_planes_k3s1(&p, np, npad, M, s);
         if (rc != -100) return rc;
     }
-    if (yv3_conv2d_planes_form(d, np) == 1) return launch_wino(d, p, s);
+    if (planes_wino_rule(d, np) == 1) return launch_wino(d, p, s);
     const bool use_pp = !(d->options & YV3_OPT_NO_PINGPONG);       // ping-pong main loop (fp16x2, 8-wave tiles) unless disabled
 #define YV3_CFG(BM_, BN_, WM_, WN_, NS_) (np == 3 ? launch_cfg<3, BM_, BN_, WM_, WN_, NS_>(p, k3, dual, out_f32, use_pp, s) : \
                                          np == 2 ? launch_cfg<2, BM_, BN_, WM_, WN_, (NS_) + 1>(p, k3, dual, out_f32, use_pp, s) : \

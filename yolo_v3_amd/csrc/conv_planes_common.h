@@ -40,6 +40,15 @@ struct ConvParamsP {
 #define YV3_WINO_SK_PART_BYTES (512 * 128 * 4)
 static inline size_t yv3_wino_sk_bytes() { return (size_t)YV3_WINO_SK_MAX_WG * (YV3_WINO_SK_PART_BYTES + sizeof(int)) + 256; }
 
+// IO ablations of the epilogue (bit 0 no stores, bit 1 no residual loads, bit 2 no decode arithmetic: results INVALID) exist only in
+// measurement builds (-DYV3_MEASURE: `make measure` / tools/build_variant.sh -> libyv3_measure.so / libyv3_<name>.so); the shipped
+// libyv3.so ignores yv3_conv_desc.tune[3] -- the branches are compiled out.
+#ifdef YV3_MEASURE
+#define YV3_IO_ABL(p) ((p).tune[3])
+#else
+#define YV3_IO_ABL(p) 0
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(64))) u16 g_zero_page[64];     // zero-initialised: source of halo rows
@@ -206,7 +215,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
     u32x4 rres[PRE ? NPASS : 1][NP];
     auto fetch_res = [&](int jg) {
         if constexpr (PRE) {
-            if (p.res && !(p.tune[3] & 2)) {
+            if (p.res && !(YV3_IO_ABL(p) & 2)) {
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const long long px = rowpix(m0 + wm * WTM + jg * GR + ps * RPP + lane / LPR);
@@ -308,9 +317,9 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
                         f32x4 dv;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            dv[q] = (p.tune[3] & 4) ? t[q] : yv3_decode_value(t[q], dattr[q], dan[q], (float)dgx, (float)dgy, p.dec_stride);
+                            dv[q] = (YV3_IO_ABL(p) & 4) ? t[q] : yv3_decode_value(t[q], dattr[q], dan[q], (float)dgx, (float)dgy, p.dec_stride);
                         float* o = p.dec_out + (long long)db * p.dec_bs + (long long)(dgy * p.Wo + dgx) * p.Cout + nd;
-                        if (p.tune[3] & 1) asm volatile("" :: "v"(dv));   // (IO ablation for measurements: results INVALID)
+                        if (YV3_IO_ABL(p) & 1) asm volatile("" :: "v"(dv));   // (IO ablation for measurements: results INVALID)
                         else if (nv >= 4) *reinterpret_cast<f32x4u*>(o) = dv;
                         else if (nv == 3) *reinterpret_cast<f32x3u*>(o) = f32x3u{dv[0], dv[1], dv[2]};
                         else { o[0] = dv[0]; if (nv > 1) o[1] = dv[1]; }
@@ -354,7 +363,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[BN / WN / 32][BM / 
                     qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
                     ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
                 }
-                if (!(p.tune[3] & 1)) {                  // (tune[3]: IO ablation for measurements only -- bit 0 no stores, bit 1 no residual loads)
+                if (!(YV3_IO_ABL(p) & 1)) {                  // (measurement builds only: IO ablation)
                     *reinterpret_cast<u32x4*>(yo) = qh;
                     *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
                 } else { asm volatile("" :: "v"(qh), "v"(ql)); }
@@ -425,7 +434,7 @@ __device__ __forceinline__ void epilogue_store_wino4(f32x16 (&yac)[4][BN / WN / 
         const int need = 1 | ((o >> 1) ? 2 : 0) | ((o & 1) ? 4 : 0);
         return (okb[ps] & need) == need ? pxb[ps] + (o >> 1) * p.wW + (o & 1) : -1;
     };
-    const bool use_res = p.res && !(p.tune[3] & 2);
+    const bool use_res = p.res && !(YV3_IO_ABL(p) & 2);
     u32x4 rres[2][NPASS][NP];
     auto fetch_res = [&](int o, int buf) {
         if (use_res) {
@@ -500,7 +509,7 @@ __device__ __forceinline__ void epilogue_store_wino4(f32x16 (&yac)[4][BN / WN / 
                 qh[h] = PlaneOps<2>::pack2_nosat(v[2 * h], v[2 * h + 1]);
                 ql[h] = PlaneOps<2>::pack2_nosat(v[2 * h] - PlaneOps<2>::lo(qh[h]), v[2 * h + 1] - PlaneOps<2>::hi(qh[h]));
             }
-            if (!(p.tune[3] & 1)) {
+            if (!(YV3_IO_ABL(p) & 1)) {
                 *reinterpret_cast<u32x4*>(yo) = qh;
                 *reinterpret_cast<u32x4*>(yo + p.ys) = ql;
             } else { asm volatile("" :: "v"(qh), "v"(ql)); }

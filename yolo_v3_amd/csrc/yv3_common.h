@@ -58,9 +58,15 @@ __device__ static inline int yv3_xcd_remap(int bid, int nblk) {
 // exp + IEEE division this replaces were 30 % of a head conv's time (profiles/r04ad_head_probe.txt).
 #ifdef __HIPCC__
 __device__ static inline float yv3_exp(float u) {
-    const float a = u * 1.44269502e+0f;                                       // log2(e) rounded to float
-    const float c = fmaf(u, 1.92596299e-8f, fmaf(u, 1.44269502e+0f, -a));     // + its tail, + the product's rounding error
-    return __builtin_amdgcn_exp2f(a) * fmaf(c, 0.693147182f, 1.0f);           // (inf * (1 + tiny) = inf, 0 * .. = 0: no NaN)
+    // arguments outside [-104, 89] already give 0 / inf in fp32 (e^-104 < the smallest denormal, e^89 > FLT_MAX): clamping there
+    // keeps +-inf and |u| > 2.36e38 (whose product with log2e overflows: inf - inf) away from the compensation term, so that
+    // exp(+inf) = inf, exp(-inf) = 0, sigmoid(+-inf) = 1 / 0 as the reference's expf / division give.  v_med3_f32
+    // returns the other two operands' minimum for a NaN input; the NaN is restored below (exp(NaN) = NaN like the reference).
+    const float uc = __builtin_amdgcn_fmed3f(u, -104.0f, 89.0f);
+    const float a = uc * 1.44269502e+0f;                                      // log2(e) rounded to float
+    const float c = fmaf(uc, 1.92596299e-8f, fmaf(uc, 1.44269502e+0f, -a));   // + its tail, + the product's rounding error
+    const float r = __builtin_amdgcn_exp2f(a) * fmaf(c, 0.693147182f, 1.0f);
+    return u != u ? u : r;
 }
 __device__ static inline float yv3_decode_value(float t, int attr, float an, float gx, float gy, float stride) {
 #pragma clang fp contract(off)

@@ -11,21 +11,20 @@ IOU masks -> scan -> compact, with no host synchronisation until ONE device-to-h
 final ``[B, cap, 7]`` boxes and their counts.  ``Detector`` keeps the buffers (and optionally a
 captured HIP graph of the whole pipeline) alive across calls.
 
-Lanes.  A batch of about 12 or more 416 x 416 images (8 at 608 x 608) runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
+Lanes.  A batch of 48 or more 416 x 416 images (23 at 608 x 608) runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
 kernels with the same K order -- bit-identical detections on the direct kernels (``net.winograd = False``); with the default
 per-launch choice between the direct and the Winograd form of a 3x3 layer (it depends on the sub-batch's tile count) the two
 schedules agree within fp32 round-off -- but the two launch sequences run concurrently
 and fill each other's partially occupied rounds of the chip (at bs=64 the 13x13 layers have 1.34 rounds of tiles,
 the 26x26 layers 2.64, ...) and overlap HBM-bound layers with matrix-bound ones: conv section 13.97 -> 12.65 ms
 (tools/lanes_probe.py).  HIP maps streams onto a few hardware queues and two streams on the SAME queue serialise
-(measured: 15.1 ms, worse than one lane), so the constructor times the candidate stream pairs on this GPU and
-keeps the fastest -- or a single lane if none wins.
+(measured: 15.1 ms, worse than one lane), so the constructor looks for a stream pair that really overlaps with a deterministic
+yes/no probe (`streams_run_concurrently`) -- or runs a single lane if there is none.  The lane count itself is a function of the
+batch shape only (TWO_LANES_MIN_PIXELS), identical on every rank of a sharded run: no stopwatch, no collective.
 """
-import time
 from collections import OrderedDict
 
 import torch
-import torch.distributed as dist
 
 from . import _ffi
 from .engine import Plan
@@ -35,11 +34,11 @@ from .utils import PostProcessor, boxes_to_list
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
                  max_cand=None, cap=None, dtype=None, graph=False, lanes=None, group=None, sync_lanes=False):
-        """lanes: 1, 2, or None = automatic (2 when the batch is at least ~12 images of 416 x 416 and a stream pair that really
-        runs concurrently is found, see the module docstring; ``net.lanes`` / YV3_LANES override the default).
-        sync_lanes: all ranks of the torch.distributed process group `group` (None = the default group) construct this
-        Detector together (`detect_sharded`); the automatic lane decision is then MIN-reduced over them so that every
-        rank runs the same lane count."""
+        """lanes: 1, 2, or None = automatic: 2 from TWO_LANES_MIN_PIXELS (48 images of 416 x 416) upwards when a stream pair that
+        really runs concurrently exists (a deterministic probe, see `concurrent_stream_pair`), else 1 -- a pure function of the
+        batch shape, no stopwatch; ``net.lanes`` overrides the default.
+        group / sync_lanes: accepted for `ShardedDetector`; the constructor contains NO collective (round 5: the lane count is
+        the same function of the shape on every rank)."""
         self.net = net
         self.shape = (batch, 3, height, width)
         self.conf, self.nms_thr, self.is_eval, self.use_nms = obj_conf_thr, nms_thr, is_eval, use_nms
@@ -49,8 +48,8 @@ class Detector:
         self._generation = self.engine.generation
         self._group, self._sync_lanes = group, bool(sync_lanes)
         if lanes is None:
-            import os
-            lanes = getattr(net, "lanes", None) or (int(os.environ["YV3_LANES"]) if os.environ.get("YV3_LANES") else None)
+            from .engine import measure_env
+            lanes = getattr(net, "lanes", None) or (int(measure_env("YV3_LANES")) if measure_env("YV3_LANES") else None)
         if self.engine.deterministic:
             lanes = 1                    # net.deterministic: one schedule whatever the batch (engine.Engine.__init__)
         self._lanes_req = lanes
@@ -64,14 +63,12 @@ class Detector:
             # ONE result tensor + ONE counts buffer ([0:B] candidates, [B:2B] kept) for all lanes: a single D2H copy
             self.boxes = torch.empty((B, self.cap, 7), device=self.device, dtype=torch.float32)
             self.counts = torch.zeros(2 * B, device=self.device, dtype=torch.int32)
-            # automatic: worth trying from ~12 images of 416 x 416 upwards (measured crossover; 608 x 608: 8), calibration decides
-            auto2 = lanes is None and batch >= 2 and batch * height * width >= 12 * 416 * 416
-            self.lane_calibration = None
+            auto2 = lanes is None and batch >= 2 and batch * height * width >= TWO_LANES_MIN_PIXELS
             if auto2:
                 self._choose_lanes()
             else:
                 self._build_plans(2 if (lanes or 1) >= 2 else 1, self.engine.lane_choices.get("stream_pair"))
-                if self.lanes == 2 and "stream_pair" not in self.engine.lane_choices:
+                if self.lanes == 2:
                     self._pick_stream_pair()              # (a requested second lane must not land on the first one's hardware queue)
         self._graph = None
         self._static_in = None
@@ -142,121 +139,19 @@ class Detector:
             mark(name)
 
     def _choose_lanes(self):
-        """Automatic lane count: time the candidate stream pairs against one lane on this GPU (streams that share a
-        hardware queue serialise and LOSE against a single lane) -- once per (engine, batch shape): the decision and the
-        winning stream pair are cached on the engine -- then agree on MIN over the ranks of `group`."""
-        key = ("lanes", self.shape, self.is_eval)
-        cached = self.engine.lane_choices.get(key)
-        if cached is None:
-            cached = self._calibrate_lanes()
-            self.engine.lane_choices[key] = cached
-        lanes, streams, self.lane_calibration = cached
-        if self._sync_lanes:
-            lanes = _min_over_group(lanes, self._group, self.device)
-        self._build_plans(lanes, streams if lanes > 1 else None)
+        """Automatic lane count: a pure function of the batch shape -- two lanes from TWO_LANES_MIN_PIXELS upwards -- provided a
+        stream pair that really runs concurrently exists on this GPU (`concurrent_stream_pair`: a yes/no probe, not a stopwatch).
+        No timing, no collective: every rank of a sharded run computes the same answer from the same shape, and `bench.py`
+        prints each rank's choice."""
+        streams = concurrent_stream_pair(self.device, self.engine.lane_choices)
+        self._build_plans(2 if streams is not None else 1, streams)
 
     def _pick_stream_pair(self):
-        """Two-lane plans are built: time three candidate stream pairs over a few steps each and keep the fastest (a pair that shares
-        a hardware queue serialises: 6.0 instead of 4.2 ms at bs=16, profiles/r03y_lanes_loop_probe.txt); remembered on the engine."""
-        x = torch.rand(self.shape, device=self.device, dtype=torch.float32, generator=torch.Generator(device=self.device).manual_seed(1234))
-        noop = lambda name: None
-        best = None
-        for pair in [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]:
+        """Two lanes were REQUESTED: they must not land on one hardware queue (they would serialise: 6.0 instead of 4.2 ms at bs=16,
+        profiles/r03y_lanes_loop_probe.txt).  Keeps the freshly made streams when no concurrent pair exists."""
+        pair = concurrent_stream_pair(self.device, self.engine.lane_choices)
+        if pair is not None:
             self.lane_streams = pair
-            for _ in range(2):
-                self._run_lanes(x, noop)
-            torch.cuda.synchronize(self.device)
-            t0 = time.perf_counter()
-            for _ in range(4):
-                self._run_lanes(x, noop)
-            torch.cuda.synchronize(self.device)
-            t = time.perf_counter() - t0
-            if best is None or t < best[0]:
-                best = (t, pair)
-        self.lane_streams = best[1]
-        self.lane_plans[0].flags.zero_()
-        self.engine.lane_choices["stream_pair"] = best[1]
-
-    def _calibrate_lanes(self):
-        B, _, H, W = self.shape
-        # image-like values, not zeros: the conv kernels' speed is data-dependent on this power-limited chip (zero operands run
-        # 25-30 % faster and favour the wrong schedule)
-        gen = torch.Generator(device=self.device).manual_seed(1234)
-        x = torch.rand(self.shape, device=self.device, dtype=torch.float32, generator=gen)
-        noop = lambda name: None
-
-        reps = 3 if B * H * W >= 40 * 416 * 416 else 8           # short steps need more repetitions for a 3 % decision
-
-        def timed(n=reps):
-            # the WHOLE pipeline (convs + decode + filter + NMS): two lanes also run two smaller, latency-bound post-processing
-            # sequences -- timing the convolutions alone chose two lanes for bs=16 and the dense 608x608 bs=8 config, where the
-            # full step is 3-4 % slower with them (profiles/r03y_lane_choice.txt)
-            for _ in range(2):
-                self._run_lanes(x, noop)
-            torch.cuda.synchronize(self.device)
-            t0 = time.perf_counter()
-            for _ in range(n):
-                self._run_lanes(x, noop)
-            torch.cuda.synchronize(self.device)
-            return (time.perf_counter() - t0) / n
-
-        def snapshot():
-            return (self.lanes, self.plan, self.lane_plans, self.lane_off, self.lane_streams, self.lane_pp)
-
-        def restore(st):
-            self.lanes, self.plan, self.lane_plans, self.lane_off, self.lane_streams, self.lane_pp = st
-
-        def steady(seconds):
-            """ms per step over at least `seconds` of back-to-back steps (host sync every 4 steps)."""
-            self._run_lanes(x, noop)
-            torch.cuda.synchronize(self.device)
-            n, t0 = 0, time.perf_counter()
-            while True:
-                for _ in range(4):
-                    self._run_lanes(x, noop)
-                n += 4
-                torch.cuda.synchronize(self.device)
-                if time.perf_counter() - t0 >= seconds:
-                    return (time.perf_counter() - t0) / n
-
-        # 1. the stream pair: short runs are enough to tell a pair that shares a hardware queue (it serialises) from one that does not
-        known = self.engine.lane_choices.get("stream_pair")
-        self._build_plans(2, known)
-        if known is None:
-            best = None
-            for pair in [self.lane_streams] + [[torch.cuda.Stream(device=self.device) for _ in range(2)] for _ in range(2)]:
-                self.lane_streams = pair
-                t = timed()
-                if best is None or t < best[0]:
-                    best = (t, pair)
-            known = self.engine.lane_choices["stream_pair"] = best[1]
-        self.lane_streams = known
-        best = (None, known)
-        two_state = snapshot()
-        had_plan = (B, H, W) in self.engine._plans
-        self._build_plans(1)
-        one_state = snapshot()
-        # 2. one lane or two: alternating runs of >= 0.15 s each.  A burst of a few steps runs at boost clocks; the sustained
-        # clock under the power limit is lower for the schedule that keeps more of the chip busy, and bursts chose two lanes for
-        # bs=16 / the dense 608x608 bs=8 config where the sustained step is 3-8 % slower with them (profiles/r03y_lane_choice.txt)
-        t1 = t2 = 0.0
-        for _ in range(2):
-            restore(one_state)
-            t1 += steady(0.15) / 2
-            restore(two_state)
-            t2 += steady(0.15) / 2
-        one_state[1].flags.zero_()
-        two_state[2][0].flags.zero_()
-        # two lanes must win by 4 %: inside a caller's loop (D2H copies of the results between the steps) they lose 1-3 % of what
-        # this loop measures and their step time scatters more (profiles/r03y_lane_choice_order.txt: bs=16 and the dense config are a
-        # wash at a measured 2-3.5 % advantage; bs=64 wins 7.5 % here and 6-7 % in the bench loop)
-        two = t2 < 0.96 * t1
-        restore(one_state)
-        if two and not had_plan:
-            self.engine.drop_plan(B, H, W)            # the one-lane plan's activation buffers are not kept alive beside the lanes'
-        del one_state, two_state
-        return (2 if two else 1, best[1] if two else None,
-                {"one_lane_ms": round(t1 * 1e3, 3), "two_lanes_ms": round(t2 * 1e3, 3)})
 
     # -- pipeline pieces (all asynchronous on the current stream)
     def _enqueue(self, x, mark=None):
@@ -323,21 +218,69 @@ class Detector:
         fits = int(meta[B:2 * B].max()) <= hc
         return meta[:2 * B], (self._host_boxes if fits else boxes), int(meta[2 * B])
 
+    def run_checked(self, imgs):
+        """run_device + fetch + status check -> (host counts, boxes); a stream-K hand-over time-out (the GPU was shared with another
+        small-batch caller, engine.StreamKTimeout) switches the schedule off for this engine and the batch is run again."""
+        from .engine import StreamKTimeout
+        for attempt in (0, 1):
+            boxes, counts = self.run_device(imgs)
+            host_counts, bx, status = self.fetch(boxes, counts)
+            try:
+                self.engine.raise_if_overflowed(self.plan, status)
+                return host_counts, bx
+            except StreamKTimeout:
+                if attempt:
+                    raise
+                self.engine.disable_stream_k()
+
     def __call__(self, imgs):
-        boxes, counts = self.run_device(imgs)
-        host_counts, bx, status = self.fetch(boxes, counts)
-        self.engine.raise_if_overflowed(self.plan, status)
+        host_counts, bx = self.run_checked(imgs)
         return self.to_list(bx, host_counts)
 
 
-def _min_over_group(value, group, device):
-    """MIN of an int over the ranks of `group` (on the backend's device: RCCL wants GPU tensors, gloo CPU ones)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return value
-    on_gpu = dist.get_backend(group) == "nccl"
-    t = torch.tensor([int(value)], dtype=torch.int32, device=device if on_gpu else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    return int(t.item())
+# Two lanes from this many input pixels per batch (48 images of 416 x 416, 23 of 608 x 608).  Measured, same box, whole pipeline,
+# sustained (profiles/r03y_lane_choice.txt, r03y_lane_choice_order.txt): bs=64 @416 +7 %, 256 images +6 %; bs=32 @416, bs=16 @416,
+# bs=16 @608 (bf16) and the dense bs=8 @608 config: -1...-4 % to +2 % depending on the run -- a wash that a 1 s stopwatch calibration
+# decided differently from box to box.  The rule is the documented threshold; `lanes=` / ``net.lanes`` override it.
+TWO_LANES_MIN_PIXELS = 48 * 416 * 416
+
+
+def streams_run_concurrently(a, b, device):
+    """Deterministic yes/no probe: does work on stream `b` start while stream `a` is busy?  HIP maps streams onto a few hardware
+    queues; two streams on the SAME queue serialise.  A spin of a few milliseconds goes to `a`, one tiny kernel to `b`: when the tiny
+    kernel has finished and the spin has not, the two streams are on different queues."""
+    with torch.cuda.device(device):
+        t = torch.zeros(64, device=device)
+        torch.cuda.synchronize(device)
+        ea, eb = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(8_000_000)            # >= 3 ms at any of the clocks the counter may run at (100 MHz ... 2.4 GHz)
+            ea.record(a)
+        with torch.cuda.stream(b):
+            t.add_(1.0)
+            eb.record(b)
+        eb.synchronize()
+        concurrent = not ea.query()
+        ea.synchronize()
+    return concurrent
+
+
+def concurrent_stream_pair(device, cache=None, tries=6):
+    """Two HIP streams of `device` that run concurrently (None when none of `tries` fresh streams pairs with the first);
+    remembered in `cache["stream_pair"]` (the engine's lane_choices: one probe per engine)."""
+    if cache is not None and "stream_pair" in cache:
+        return cache["stream_pair"]
+    pair = None
+    with torch.cuda.device(device):
+        first = torch.cuda.Stream(device=device)
+        for _ in range(tries):
+            other = torch.cuda.Stream(device=device)
+            if streams_run_concurrently(first, other, device) and streams_run_concurrently(other, first, device):
+                pair = [first, other]
+                break
+    if cache is not None:
+        cache["stream_pair"] = pair
+    return pair
 
 
 def _detector_cache(net):
@@ -350,10 +293,9 @@ DETECTOR_CACHE_MAX = 3
 
 
 def cached_detector(net, key, build, sharded=False):
-    """`sharded`: detectors of `detect_sharded` live in their OWN least-recently-used cache.  Building one contains a
-    collective (the MIN-reduction of the lane count), so every rank must build -- and therefore evict -- at the same calls:
-    this cache only ever sees the sharded calls, which all ranks issue in the same order with the same keys, whereas the
-    rank-local `detect()` / `predict()` calls of one rank can no longer push a sharded detector out on that rank alone."""
+    """`sharded`: detectors of `detect_sharded` live in their OWN least-recently-used cache: it only ever sees the sharded calls,
+    which all ranks issue in the same order with the same keys, so the rank-local `detect()` / `predict()` calls of one rank cannot
+    push a sharded detector (its payload buffers are the collective's registered memory) out on that rank alone."""
     cache = net.__dict__.setdefault("_sharded_detectors", OrderedDict()) if sharded else _detector_cache(net)
     det = cache.get(key)
     if det is None:
@@ -380,9 +322,7 @@ def detect(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, is_eval=F
     with torch.no_grad():
         if not is_eval:
             return det(imgs)
-        boxes, counts = det.run_device(imgs)
-        host_counts, bx, status = det.fetch(boxes, counts)
-        det.engine.raise_if_overflowed(det.plan, status)
+        host_counts, bx = det.run_checked(imgs)
         B = imgs.shape[0]
         if int(host_counts[:B].max()) <= det.max_cand and int(host_counts[B:2 * B].max()) <= det.cap:
             return det.to_list(bx, host_counts)

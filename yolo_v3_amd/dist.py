@@ -167,7 +167,9 @@ class ShardedDetector:
         self.group, self.force = group, force_collective
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
-        # every rank builds this together: the automatic lane count is MIN-reduced over the group (rank-consistent)
+        # no collective in here: the automatic lane count is a function of the batch shape (detect.TWO_LANES_MIN_PIXELS), the same
+        # on every rank; a rank without a concurrent stream pair runs one lane (same boxes within fp32 round-off, `net.deterministic`
+        # for identical bits) and says so in bench.py's per-rank table
         self.det = Detector(net, b_pad, height, width, obj_conf_thr, nms_thr, False, use_nms, cap=cap, dtype=dtype,
                             lanes=lanes, group=group, sync_lanes=on and self.world > 1)
         self.b_pad = b_pad

@@ -58,6 +58,10 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class StreamKTimeout(_ffi.Yv3Error):
+    """The kernels' status bit 1: a stream-K hand-over did not arrive (see Engine.raise_if_overflowed)."""
+
+
 class PackedConv:
     """Device-side parameters of one convolution in kernel layout."""
     __slots__ = ("spec", "w", "alpha", "beta", "cout_pad", "w_wino", "alpha_wino")
@@ -74,12 +78,21 @@ def conv_params(module):
     return module.conv.weight, module.bn, None
 
 
-WINO_MIN_CIN = int(os.environ.get("YV3_WINO_MIN_CIN", "256") or 256)     # Winograd F(2x2,3x3) for 3x3 / stride-1 layers with at least this many input channels (26x26 and 13x13 at
+def measure_env(name, default=None):
+    """Tuning / A-B overrides from the environment are honoured ONLY in measurement sessions (YV3_MEASURE=1, set by tools/gpu.sh): in
+    normal use a stray YV3_* variable changes nothing -- kernel selection is a function of the descriptor, the product knobs are
+    attributes of the net (net.math_mode, .stream_k, .winograd, .deterministic, .lanes, ...)."""
+    if os.environ.get("YV3_MEASURE") != "1":
+        return default
+    return os.environ.get(name, default)
+
+
+WINO_MIN_CIN = int(measure_env("YV3_WINO_MIN_CIN", "256") or 256)     # Winograd F(2x2,3x3) for 3x3 / stride-1 layers with at least this many input channels (26x26 and 13x13 at
                        # 416x416): below, the transformed input (16 B per input element through HBM) costs more than the MFMAs saved
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
-SK_AUTO_CELLS = int(os.environ.get("YV3_SK_AUTO_CELLS", "1536") or 1536)     # stream-K by default up to this many 32x32 cells per batch (Plan.__init__)
+SK_AUTO_CELLS = int(measure_env("YV3_SK_AUTO_CELLS", "1536") or 1536)     # stream-K by default up to this many 32x32 cells per batch (Plan.__init__)
 
 
 WINO_MIN_CIN_F32 = 64  # exact-fp32 mode: fp32 MFMA runs at the vector rate, every 3x3 layer is matrix-bound -> from the 104x104 layers down
@@ -166,18 +179,19 @@ def pack_conv(module, spec, dtype, winograd=False):
 
 def tuning_options():
     """Kernel-selection overrides for A/B measurements (tools/): read from the environment HERE, on the host side of
-    the C-ABI, and passed in yv3_conv_desc.options / .big_tile_min -- the library itself reads no environment."""
+    the C-ABI, and passed in yv3_conv_desc.options / .big_tile_min -- the library itself reads no environment.  Only with
+    YV3_MEASURE=1 (measure_env)."""
     opts = 0
-    if os.environ.get("YV3_NO_PP"):
+    if measure_env("YV3_NO_PP"):
         opts |= _ffi.OPT_NO_PINGPONG
-    if os.environ.get("YV3_K3S1"):
+    if measure_env("YV3_K3S1"):
         opts |= _ffi.OPT_K3S1
-    if os.environ.get("YV3_WINO_EVEN"):
+    if measure_env("YV3_WINO_EVEN"):
         opts |= _ffi.OPT_WINO_EVEN
-    if os.environ.get("YV3_WINO_ALWAYS"):
+    if measure_env("YV3_WINO_ALWAYS"):
         opts |= _ffi.OPT_WINO_ALWAYS
-    opts |= (int(os.environ.get("YV3_TILE", "0") or 0) & 0xff) << 8
-    return opts, int(os.environ.get("YV3_BIG_MIN", "0") or 0)
+    opts |= (int(measure_env("YV3_TILE", "0") or 0) & 0xff) << 8
+    return opts, int(measure_env("YV3_BIG_MIN", "0") or 0)
 
 
 def batch_split(B, ho, wo, cout_pad, ncu):
@@ -215,7 +229,7 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
         d.options |= _ffi.OPT_TWO_LANES
     if wino_always:
         d.options |= _ffi.OPT_WINO_ALWAYS
-    for i, v in enumerate((os.environ.get("YV3_TUNE", "") or "0").split(",")[:4]):
+    for i, v in enumerate((measure_env("YV3_TUNE", "") or "0").split(",")[:4]):
         d.tune[i] = int(v or 0)
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
     d.alpha, d.beta = _ptr(pc.alpha), _ptr(pc.beta)
@@ -457,27 +471,27 @@ class Engine:
         # chip has CUs, splitting their K ranges over the idle CUs cuts a single image's latency 2.25 -> 1.75 ms and gains 17 % at
         # bs=4); True / YV3_SK=1: wherever the library's shape rule applies; False / YV3_SK=0: never
         sk = getattr(net, "stream_k", None)
-        if sk is None and os.environ.get("YV3_SK") in ("0", "1"):
-            sk = os.environ["YV3_SK"] == "1"
+        if sk is None and measure_env("YV3_SK") in ("0", "1"):
+            sk = measure_env("YV3_SK") == "1"
         self.stream_k = None if sk is None else bool(sk)
-        self.fuse_decode = bool(getattr(net, "fuse_decode", os.environ.get("YV3_NO_FUSED_DECODE") is None))
-        self.fuse_front = bool(getattr(net, "fuse_front", os.environ.get("YV3_NO_FUSED_FRONT") is None))
-        self.fuse_res64 = bool(getattr(net, "fuse_res64", os.environ.get("YV3_NO_FUSED_RES64") is None))
+        self.fuse_decode = bool(getattr(net, "fuse_decode", measure_env("YV3_NO_FUSED_DECODE") is None))
+        self.fuse_front = bool(getattr(net, "fuse_front", measure_env("YV3_NO_FUSED_FRONT") is None))
+        self.fuse_res64 = bool(getattr(net, "fuse_res64", measure_env("YV3_NO_FUSED_RES64") is None))
         # opt-in (measured null end to end, see batch_split): 13x13 layers as "one full round" + "the rest"
-        self.batch_split = bool(getattr(net, "batch_split", os.environ.get("YV3_BATCH_SPLIT") == "1"))
+        self.batch_split = bool(getattr(net, "batch_split", measure_env("YV3_BATCH_SPLIT") == "1"))
         # Winograd F(2x2,3x3) for the 3x3 stride-1 layers with >= 256 input channels (fp16-plane mode; csrc/winograd.hip)
         # (default on: the library uses it per launch when the tile count suits it, yv3_conv_desc.w_wino; YV3_WINO=0 / net.winograd = False: never)
         # net.winograd = "always" (YV3_WINO=always): on every eligible layer whatever the tile count (parity tests of the form itself)
         wino = getattr(net, "winograd", None)
         if wino is None:
-            env = os.environ.get("YV3_WINO", "1")
+            env = measure_env("YV3_WINO", "1")
             wino = "always" if env == "always" else env != "0"
-        self.wino_always = wino == "always" or bool(os.environ.get("YV3_WINO_ALWAYS"))
+        self.wino_always = wino == "always" or bool(measure_env("YV3_WINO_ALWAYS"))
         self.winograd = bool(wino)
         # net.deterministic = True: ONE switch for "the same image gives the same bits at every batch size, batch position and lane
         # count": direct one-tile-per-workgroup kernels only (no per-launch Winograd choice, no stream-K split tiles); `Detector`
         # then also runs a single lane.  Costs ~10 % at bs=64.
-        self.deterministic = bool(getattr(net, "deterministic", os.environ.get("YV3_DETERMINISTIC") == "1"))
+        self.deterministic = bool(getattr(net, "deterministic", measure_env("YV3_DETERMINISTIC") == "1"))
         if self.deterministic:
             self.winograd, self.wino_always, self.stream_k = False, False, False
 
@@ -488,20 +502,27 @@ class Engine:
         tensors themselves are re-read from them each time, so re-assigned parameters are still seen."""
         slots = self.__dict__.get("_mod_slots")
         if slots is not None:
-            # a cached module is only trusted while its parent still holds the SAME object under the same name (75 dict
-            # look-ups, ~10 us): a replaced submodule (net.pre_det1.mlist[6] = nn.Conv2d(...)) is re-resolved -- and, its
-            # tensors being new objects, changes the signature
-            for reg, key, m in slots:
+            # a cached module is only trusted while EVERY container on its path from the root still holds the same child under the
+            # same name: the distinct (registry, key, child) links of all 75 paths (~110 dict look-ups, ~15 us) are re-checked, so a
+            # replaced leaf (net.pre_det1.mlist[6] = nn.Conv2d(...)), a replaced container (net.pre_det1 = PreDetectionConvGroup(...))
+            # or a replaced ModuleList (net.pre_det1.mlist = nn.ModuleList(...)) is re-resolved -- and, its tensors being new
+            # objects, changes the signature (ADVICE r4: the leaf's parent alone is not enough)
+            for reg, key, m in self._mod_links:
                 if reg.get(key) is not m:
                     slots = None
                     break
         if slots is None:
-            slots = []
+            slots, links, seen = [], [], set()
             for sp in self.specs:
-                parent, _, leaf = sp.name.rpartition(".")
-                pm = self.net.get_submodule(parent) if parent else self.net
-                slots.append((pm._modules, leaf, pm._modules[leaf]))
-            self._mod_slots = slots
+                node = self.net
+                for part in sp.name.split("."):
+                    child = node._modules[part]
+                    if (id(node._modules), part) not in seen:
+                        seen.add((id(node._modules), part))
+                        links.append((node._modules, part, child))
+                    node = child
+                slots.append((None, None, node))
+            self._mod_slots, self._mod_links = slots, links
         out = []
         for _, _, m in slots:                        # (straight from the modules' dicts: nn.Module.__getattr__ is slow)
             if isinstance(m, torch.nn.Conv2d):
@@ -656,12 +677,23 @@ class Engine:
             plan.flags_host.zero_()
             plan.flags_event = None
             if flag_value & 2:
-                raise _ffi.Yv3Error("internal error: a stream-K accumulator hand-over timed out (the stream-K schedule is automatic "
-                                    "for small batches and opt-in otherwise: set net.stream_k = False or YV3_SK=0 -- or "
-                                    "net.deterministic = True -- to disable it, and report)")
+                raise StreamKTimeout("a stream-K accumulator hand-over timed out: the schedule needs all of its workgroups resident at once "
+                                     "and something else (another stream / thread / process running small batches) held part of the GPU.  "
+                                     "Callers that share the GPU set net.stream_k = False (or net.deterministic = True)")
             raise _ffi.Yv3Error(self.OVERFLOW_MSG_BF16 if self.dtype == BF16 else self.OVERFLOW_MSG)
 
-    def forward(self, x, dets=None):
+    def disable_stream_k(self):
+        """After a StreamKTimeout: this engine stops using the stream-K schedule (plans are rebuilt without its workspace; holders
+        of a Plan -- `Detector` -- see the new `generation`).  The results of the call that timed out are invalid and must be
+        recomputed by the caller (`forward`, `Detector.__call__` and `detect` do)."""
+        import warnings
+        warnings.warn("yolo_v3_amd: stream-K hand-over timed out (the GPU is shared with another small-batch caller); the stream-K "
+                      "schedule is now off for this network -- set net.stream_k = False to avoid the first slow call", RuntimeWarning)
+        self.stream_k = False
+        self._plans = {}
+        self.generation += 1
+
+    def forward(self, x, dets=None, _retry=True):
         """x: [B,3,H,W] fp32 on the GPU -> detections [B, N, 5+C] (cx,cy,w,h,conf,cls...).
 
         In F32H2 mode (and BF16, whose first layer splits its operands into fp16) the kernels' saturation flag of THIS call is copied to pinned host memory behind the last
@@ -688,5 +720,11 @@ class Engine:
                 plan.flags_event.record()
                 if not getattr(self.net, "async_forward", False):
                     plan.flags_event.synchronize()
-                    self.raise_if_overflowed(plan, int(plan.flags_host[0]))
+                    try:
+                        self.raise_if_overflowed(plan, int(plan.flags_host[0]))
+                    except StreamKTimeout:
+                        if not _retry:
+                            raise
+                        self.disable_stream_k()               # (fall back instead of failing the call)
+                        return self.forward(x, dets, _retry=False)
         return dets, plan

@@ -126,10 +126,14 @@ def predict_and_process(data, net, num_classes, batch_handler=None, obj_conf_thr
 
 def read_image_rgb(path):
     """uint8 RGB [H,W,3] of an image file (the reference reads with ``cv2.imread`` + BGR->RGB, evaluate.py:136-137; cv2 is not a
-    dependency here: PIL decodes -- JPEG decoders may differ from OpenCV's by an LSB on some pixels)."""
+    dependency here: PIL decodes -- JPEG decoders may differ from OpenCV's by an LSB on some pixels).  ``cv2.imread`` applies the
+    file's EXIF orientation by default (IMREAD_COLOR without IMREAD_IGNORE_ORIENTATION); PIL does not, so it is applied here
+    (``ImageOps.exif_transpose``): COCO holds JPEGs with an orientation tag, and both the pixels fed to the network and the
+    org_w / org_h the boxes are mapped back with must be the rotated image's, as in the reference."""
     import numpy as np
-    from PIL import Image
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
+        im = ImageOps.exif_transpose(im)
         return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
 
 
