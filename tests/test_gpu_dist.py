@@ -93,7 +93,11 @@ def test_bench_two_ranks_on_this_gpu_over_gloo():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["entry"].startswith("ShardedDetector.run_device") and "[8, 513, 7]" in out["config"]["collective"]
-    assert out["value"] > 0 and "gather" in out["stages_ms"] and len(out["config"]["boxes_kept_first_images"]) == 4
+    assert len(r.stdout.strip().splitlines()[-1]) < 4096                        # the compact line the driver parses
+    full = json.load(open(os.path.join(repo, out["full"])))                     # everything else: the side file
+    assert full["n_gpus"] == 2 and full["value"] == out["value"]
+    assert out["value"] > 0 and "gather" in full["stages_ms"] and len(full["config"]["boxes_kept_first_images"]) == 4
+    assert [r_["lanes"] for r_ in out["ranks"]] == [1, 1]
 
 
 def test_yv3_gather_boxes_is_one_rccl_allgather():
