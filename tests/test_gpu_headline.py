@@ -208,11 +208,13 @@ def test_form_query_mirrors_the_launch_dispatch(sw1_stream, monkeypatch):
     monkeypatch.setenv("YV3_K3S1", "1")
     net = load_sw1_net(sw1_stream).cuda()
     net.winograd = "always"
+    net.engine().ensure_packed()
     plan = net.engine().plan(4, 416, 416)
     assert sum(f for _, f in plan.forms()) == 0
     monkeypatch.delenv("YV3_K3S1")
     net2 = load_sw1_net(sw1_stream).cuda()
     net2.winograd = "always"
+    net2.engine().ensure_packed()
     plan2 = net2.engine().plan(4, 416, 416)
     forms = plan2.forms()
     assert sum(f for _, f in forms) == 18

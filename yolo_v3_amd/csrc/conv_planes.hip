@@ -893,6 +893,7 @@ extern "C" int yv3_merge_planes(const void* in, float* out, long long n, int np,
 }
 
 int yv3_conv2d_planes_k3s1(const ConvParamsP* pp, int np, int npad, long long M, hipStream_t s);
+int yv3_conv2d_planes_w4(const ConvParamsP* pp, int np, int npad, hipStream_t s);
 int yv3_wino_input_transform(const u16* x, long long xs, u16* v, int B, int H, int W, int C, hipStream_t s);
 
 // Winograd F(2x2,3x3) form of a 3x3 / stride-1 fp16-plane layer: input transform (winograd.hip) + the 16-position GEMM with the
@@ -1078,6 +1079,11 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         const bool sk_ok = np == 2 && p.ws && use_pp;
         const int big_min = d->big_tile_min > 0 ? d->big_tile_min : 128;
         const int force = (int)((d->options >> YV3_OPT_TILE_SHIFT) & 0xffu);
+        // (code 12: the four-wave 256x128 tile with 16-deep chunks, two workgroups per CU -- conv_planes_w4.hip)
+        if (np == 2 && force == 12 && !out_f32 && !dual) {
+            const int rc = yv3_conv2d_planes_w4(&p, np, npad, s);
+            if (rc != -100) return rc;
+        }
         if (np == 2 && force == 3) return launch_cfg<2, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         if (np == 1 && force == 3) return launch_cfg<1, 128, 128, 2, 2, 2, 2>(p, k3, dual, out_f32, false, s);
         // 256x128 tile on FOUR waves (128x64 wave tiles: 6 fragment reads per 8 MFMAs instead of 4 per 4), two workgroups per CU
