@@ -3,6 +3,7 @@
 // (per CU its own 64 KB window, re-read every iteration) with 8 loads in flight per wave.
 //   rows64   lane -> 16 rows x 64 B (the conv kernels' pixel-side pattern: 16 half lines per instruction)
 //   rows128  lane ->  8 rows x 128 B (full lines)
+//   rows32   lane -> 32 rows x 32 B (round 5: the four-wave kernel's 16-deep chunks)
 //   linear   1 KB contiguous (the packed weights' pattern)
 // build: hipcc --offload-arch=gfx950 -O3 -w -o tools/probes/dma_rate tools/probes/dma_rate.hip
 #include <hip/hip_runtime.h>
@@ -21,6 +22,7 @@ __global__ __launch_bounds__(1024) void dma_kernel(const unsigned char* src, uns
     long long off;
     if (PAT == 0) off = (lane >> 2) * 512 + (lane & 3) * 16;            // 16 rows, 512 B apart, 64 B each
     else if (PAT == 1) off = (lane >> 3) * 1024 + (lane & 7) * 16;       // 8 rows, 1 KB apart, 128 B each
+    else if (PAT == 3) off = (lane >> 1) * 256 + (lane & 1) * 16;        // 32 rows, 256 B apart, 32 B each (16-deep K chunks: conv_planes_w4.hip)
     else off = lane * 16;
     u32x4 acc = {0u, 0u, 0u, 0u};
     for (int it = 0; it < iters; ++it) {
@@ -67,6 +69,7 @@ int main() {
     for (int waves : {1, 2, 4, 8, 16}) {
         run<0, true>("rows64", waves, src, dout, ncu, win);
         run<1, true>("rows128", waves, src, dout, ncu, win);
+        run<3, true>("rows32", waves, src, dout, ncu, win);
         run<2, true>("linear", waves, src, dout, ncu, win);
         run<0, false>("rows64", waves, src, dout, ncu, win);
         run<2, false>("linear", waves, src, dout, ncu, win);

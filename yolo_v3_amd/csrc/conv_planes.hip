@@ -1097,6 +1097,25 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         // and 128x256 on eight, profiles/r04aa_bf16_192row_tiles_ab.log)
         if (np == 1 && force == 11 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
+        // Round 5: the four-wave 192x128 tile, TWO workgroups per CU (conv_planes_w4.hip): one workgroup's prologue / epilogue / launch gap
+        // under the other's main loop; bit-identical to the eight-wave tile (same K order).  Same-box A/B, bs=64 (profiles/r05e_w4_192x128_ab.txt):
+        // 128->256 @52 +4 %, 64->128 @104 +5 %, 512->256 1x1 @26 +12 %, 256->128 1x1 @52 +6 %, 512->1024 s2 @13 +11 %; at bs=32 256->512 @26
+        // +16 %, 512->1024 @13 +9 % (192-row tiles fill the chip's last round better); 256->512 @26 bs=64 -3 %, long K (512->256 3x3 @52) -5 %.
+        // (tune[1] bit 5: off, bit 6: off for 1x1 layers, bit 7: off for 3x3 layers -- A/B measurements)
+        // End to end (profiles/r05h_w4_end_to_end_ab_other_batches.txt, r05j_*): 416x416 bs=16 +7.7 %, bs=32 +3.8 %, bs=8 +2.3 %, 608x608 bs=16 +4 %,
+        // dense 608x608 bs=8 +3.4 %, bs=64 on one lane +0.8 % (the chip is power-limited there: 16 % more tile rows per CU-cycle by the kernel's own
+        // timeline, profiles/r05f_w4_timeline.txt, buy 4 % in isolation and ~1 % in the network).  Under TWO concurrent lanes the 3x3 layers lose
+        // with it (bs=64: -1.2 %; three alternating passes) while the 1x1 layers still gain (+0.2 %): there only the 1x1 layers take it.
+        const bool w4_lanes_ok = !(d->options & YV3_OPT_TWO_LANES) || !k3 || (p.tune[1] & 256);
+        if (np == 2 && force == 0 && !out_f32 && !dual && !(p.tune[1] & 32) && (k3 || p.nk >= 8) && !(p.tune[1] & (k3 ? 128 : 64)) && w4_lanes_ok) {
+            const long long t192 = ((M + 191) / 192) * (npad / 128);
+            // from three quarters of a workgroup per CU upwards (512->1024 @19x19 bs=8: 128 tiles on 256 CUs, one four-wave workgroup on
+            // every other CU, 219 instead of 292 TFLOP/s; 232 tiles @13x13 bs=32: +5 %; profiles/r05i_w4_layers_*.txt)
+            if (t192 * 4 >= 3 * yv3_num_cu()) {
+                const int rc = yv3_conv2d_planes_w4(&p, np, npad, s);
+                if (rc != -100) return rc;
+            }
+        }
         // short-K 1x1 layers (K <= 512: 8-16 chunks per tile, mostly prologue / epilogue): two independent 4-wave workgroups
         // per CU (128x128 tiles, 2-deep ring) hide each other's IO -- in the network at bs=64 the step gains 0.8 %
         // (13.31 -> 13.20 ms, same box, alternating; K = 1024 does not gain); same K order, same bits
