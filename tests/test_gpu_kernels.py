@@ -504,6 +504,43 @@ def test_conv_bf16_tile_variants_agree_bitwise(cin, cout, s, B, H, W, selected):
         assert_close_rel(out, _ref_cbr(m.cpu(), xn), 2e-2, "bf16 192-row tile %s" % ((cin, cout, s),))
 
 
+@pytest.mark.parametrize("cin,cout,k,s,B,H,W,res", [(128, 256, 3, 1, 64, 52, 52, True), (64, 128, 3, 1, 7, 104, 104, True), (256, 512, 3, 2, 9, 37, 41, False),
+                                                      (512, 256, 1, 1, 33, 26, 26, False), (256, 128, 1, 1, 16, 52, 52, False), (512, 1024, 3, 1, 32, 13, 13, True),
+                                                      (128, 256, 3, 1, 1, 11, 17, True)])
+def test_conv_w4_tile_equals_eight_wave_tile_bitwise(cin, cout, k, s, B, H, W, res):
+    """Round 5: the four-wave 192x128 tile with two workgroups per CU (csrc/conv_planes_w4.hip; tile code 12, and the shipped rule from
+    three quarters of a workgroup per CU upwards) only changes the schedule: same K order and the same three-product order per
+    k-step as the eight-wave 256x128 / 128x128 tiles (codes 1, 2), so the outputs must agree BIT FOR BIT -- 3x3 stride 1 / 2, 1x1,
+    with and without residual, M tails (173056 = 901 x 192 + 64 rows; 9 x 19 x 21 rows; a single 11 x 17 image: one partial tile) --
+    and the default selection must equal them too; one small shape is also checked against fp64."""
+    m = _rand_cbr(cin, cout, k, s, seed=cin + cout + k).cuda()
+    sp = m._spec()
+    pc = engine.pack_conv(m, sp, _ffi.F32H2)
+    xn = torch.rand(B, cin, H, W, generator=torch.Generator().manual_seed(5)) * 2 - 0.5
+    x = engine.to_planes(xn.cuda().permute(0, 2, 3, 1).contiguous(), _ffi.F32H2)
+    ho, wo = engine.out_hw(H, W, k, s)
+    rn = (torch.rand(B, cout, ho, wo, generator=torch.Generator().manual_seed(6)) - 0.5) if res else None
+    r = engine.to_planes(rn.cuda().permute(0, 2, 3, 1).contiguous(), _ffi.F32H2) if res else None
+    outs = {}
+    for code in (0, 12, 1, 2, "rule off"):
+        y = engine.alloc_act(B, ho, wo, cout, _ffi.F32H2, "cuda")
+        y.zero_()
+        d = engine.make_desc(pc, x, y, B, H, W, r, dtype=_ffi.F32H2)
+        if code == "rule off":
+            d.tune[1] = 32
+        else:
+            d.options = (d.options & ~(0xff << 8)) | (code << 8)
+        _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+        outs[code] = y
+    torch.cuda.synchronize()
+    for code, y in outs.items():
+        assert torch.equal(y, outs[12]), "tile %s differs from the four-wave 192x128 tile" % (code,)
+    if B * ho * wo <= 8192:
+        out = engine.from_planes(outs[12], _ffi.F32H2).permute(0, 3, 1, 2).cpu()
+        ref = _ref_cbr(m.cpu(), xn) + (rn.double() if res else 0.0)
+        assert_close_rel(out, ref, 2e-5, "w4 tile %s" % ((cin, cout, k, s),))
+
+
 @pytest.mark.parametrize("cin,cout,B,H,W", [(128, 256, 5, 13, 13), (64, 128, 70, 26, 26), (32, 64, 2, 19, 21), (512, 1024, 24, 13, 13), (256, 512, 33, 26, 26)])
 def test_conv_k3s1_tap_reuse_kernel(cin, cout, B, H, W, monkeypatch):
     """Opt-in 3x3/stride-1 kernel that stages ONE activation tile per (kh, channel chunk) and reuses it for

@@ -28,8 +28,13 @@ for name in names:
     m = conv_bn_relu(cin, cout, k, s).cuda().eval()
     pc = engine.pack_conv(m, m._spec(), dt)
     ho, wo = engine.out_hw(H, H, k, s)
-    x = engine.to_planes(torch.rand(B, H, H, cin, device="cuda") - 0.5, dt)
-    r = engine.to_planes(torch.rand(B, ho, wo, cout, device="cuda") - 0.5, dt) if res else None
+    zero = os.environ.get("ZERO") == "1"            # all-zero operands: the matrix pipes draw far less power, the chip is no longer power-limited
+    if zero:
+        with torch.no_grad():
+            m.conv.weight.zero_()
+        pc = engine.pack_conv(m, m._spec(), dt)
+    x = engine.to_planes((torch.rand(B, H, H, cin, device="cuda") - 0.5) * (0.0 if zero else 1.0), dt)
+    r = engine.to_planes((torch.rand(B, ho, wo, cout, device="cuda") - 0.5) * (0.0 if zero else 1.0), dt) if res else None
     fl = 2.0 * B * ho * wo * cout * cin * k * k
     descs, outs = [], []
     for v in variants:

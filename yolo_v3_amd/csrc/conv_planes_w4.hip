@@ -39,6 +39,10 @@ constexpr int W4_AQ = W4_BM / 4 / RPG;          // pixel-side DMA wave instructi
 constexpr int W4_BQ = W4_BN / 4 / RPG;          // weight side (32 rows = 2 x 16)
 constexpr int W4_G = 2 * (W4_AQ + W4_BQ);       // DMA wave instructions per chunk and wave (10)
 
+#ifndef YV3_W4_SPLIT_DMA
+#define YV3_W4_SPLIT_DMA 1                      // (0: all ten DMA pieces behind the first MFMAs of k-step 1 -- A/B builds)
+#endif
+
 template <int N> __device__ __forceinline__ void w4_wait_lgkmcnt() { __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8)); }
 
 template <bool K3, int MTG>
@@ -194,8 +198,10 @@ __global__ __launch_bounds__(256, 2) void conv_planes_w4_kernel(const ConvParams
         const bool next = STEADY || kc + 1 < p.nk;
         const bool more = STEADY || kc + W4_NS < p.nk;
         // ---- k-step 0 from registers; behind its first MFMAs the reads of k-step 1's fragments (same stage)
+        const bool wpend = YV3_W4_SPLIT_DMA && kc >= 1 && (STEADY || kc + 1 < p.nk);     // weight pieces of chunk kc+1, prepared one body ago
         kstep(I0{}, [&](int mi) {
             if (mi < NF) read_frag(st, 1, mi);
+            if (wpend && mi < NP * W4_BQ) dma_piece(NP * W4_AQ + mi);
         });
         W4_MARK(tl_k0);
         // ---- the chunk's barrier: every wave has taken all it needs from this chunk's stage; my pieces of chunk kc+1 have landed
@@ -210,15 +216,21 @@ __global__ __launch_bounds__(256, 2) void conv_planes_w4_kernel(const ConvParams
         }
         if (more) dma_prepare(kc + W4_NS, cur);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- k-step 1; behind its MFMAs the refill of this stage (chunk kc+2) and the next chunk's k-step-0 fragments
+        // ---- k-step 1; behind its MFMAs the refill of this stage (chunk kc+2) and the next chunk's k-step-0 fragments.  The four waves
+        // leave the barrier together: ten DMA pieces per wave behind the first MFMAs are 40 KB for the CU's one texture-address path
+        // (1 KB per ~16 cycles, tools/probes/dma_rate.hip) inside ~300 cycles, and the waves' issue stalls behind it (k-step 1 took 1690
+        // cycles against k-step 0's 700 with the same 18 MFMAs, profiles/r05f_w4_timeline.txt).  YV3_W4_SPLIT_DMA: only the six pixel
+        // pieces go out here; the four weight pieces (L2-resident lines: short latency) follow behind the first MFMAs of the NEXT
+        // chunk's k-step 0, still half a chunk before the barrier that needs them.
         kstep(I1{}, [&](int mi) {
-            if (more && mi < W4_G) dma_piece(mi);
+            if (more && mi < (YV3_W4_SPLIT_DMA ? NP * W4_AQ : W4_G)) dma_piece(mi);
             if (next && mi < NF) read_frag(st_next, 0, mi);
         });
         W4_MARK(tl_k1);
         cur ^= 1;
     };
-    int kc = 0;
+    body(0, std::false_type{});
+    int kc = 1;
     for (; kc + W4_NS < p.nk; ++kc) body(kc, std::true_type{});
     for (; kc < p.nk; ++kc) body(kc, std::false_type{});
 
