@@ -67,7 +67,11 @@ DTYPE_NAME = {"f32": "f32 (exact fp32 MFMA)", "bf16": "bf16 (fp32 accumulate)",
 MFMAS_PER_PRODUCT = {"f32": 1, "bf16": 1, "f32x3": 6, "f32h2": 3}
 INSTR_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0, "f32h2": 2500.0}   # dense peak of the MFMA the mode issues
 KERNEL_NAME = {"f32": "conv_igemm_f32_kernel", "bf16": "conv_planes_kernel<1>", "f32x3": "conv_planes_kernel<3>",
-               "f32h2": "conv_planes_kernel<2>"}
+               "f32h2": "conv_planes_kernel<2> + conv_planes_w4_kernel"}
+# kernels that make up the dominant family per mode (substring match on the rocprofv3 kernel names of the PMC child passes): the plane modes run the
+# eight-wave / Winograd kernels of conv_planes.hip AND, since round 5, the four-wave two-workgroups-per-CU kernel of conv_planes_w4.hip
+FAMILY = {"f32": ("conv_igemm_f32_kernel",), "bf16": ("conv_planes_kernel", "conv_planes_w4_kernel"),
+          "f32x3": ("conv_planes_kernel", "conv_planes_w4_kernel"), "f32h2": ("conv_planes_kernel", "conv_planes_w4_kernel")}
 STAGES = ("conv0", "convs", "decode", "filter", "nms")
 
 
@@ -374,6 +378,11 @@ def attach_traffic(roof, dtype, size, B, n_desc):
                                 "gfx950 calibration in MI355X_MICROARCH.md" % n_desc)
 
 
+def _in_family(kernel_name, family):
+    """`family`: one substring or a tuple of them (a kernel belongs when its name contains any)."""
+    return any(f in kernel_name for f in ((family,) if isinstance(family, str) else family))
+
+
 def sum_counter(csv_path, family, counter=None):
     """(sum of Counter_Value, number of dispatches) over the kernels of `family` in a rocprofv3 counter_collection.csv
     (`counter`: only rows of that counter, for passes that collect several)."""
@@ -381,7 +390,7 @@ def sum_counter(csv_path, family, counter=None):
     per = {}
     with open(csv_path) as f:
         for r in csv.DictReader(f):
-            if family in r["Kernel_Name"] and (counter is None or r["Counter_Name"] == counter):
+            if _in_family(r["Kernel_Name"], family) and (counter is None or r["Counter_Name"] == counter):
                 per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     return sum(per.values()), len(per)
 
@@ -392,7 +401,7 @@ def family_wall_ns(trace_csv, family):
     tot = 0
     with open(trace_csv) as f:
         for r in csv.DictReader(f):
-            if family in r["Kernel_Name"]:
+            if _in_family(r["Kernel_Name"], family):
                 tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return tot
 
@@ -424,7 +433,7 @@ def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=Non
         return False
     dtype, size, weights = dtype or args.dtype, size or args.size, weights or args.weights
     conf, nms = args.conf if conf is None else conf, args.nms if nms is None else nms
-    fam = KERNEL_NAME[dtype].split("<")[0]
+    fam = FAMILY[dtype]
     sums = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -475,13 +484,13 @@ def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=Non
         roof["clock_ghz"] = round(cyc / wall, 3)
         roof["mfma_util_note"] = ("PMC, third child pass of the same one-lane workload: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) "
                                   "over the launches of %s; clock = GRBM_GUI_ACTIVE/8 / their wall time (2.4 GHz nominal: the matrix pipe's "
-                                  "share of the nominal peak is mfma_util * clock_ghz / 2.4)" % fam)
+                                  "share of the nominal peak is mfma_util * clock_ghz / 2.4)" % " + ".join(fam))
     roof["traffic"] = round((2 * f + w) * 1024 / nf)
     roof["traffic_source"] = "measured in this run"
     roof["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / %d profiled launches of %s: rocprofv3 --pmc "
                             "passes (one counter each; a third pass for the matrix pipe) over 3 one-lane steps of this workload in child processes, %.0f s; FETCH_SIZE "
                             "doubled per the gfx950 calibration in MI355X_MICROARCH.md; algorithmic bytes per launch: flop-independent, "
-                            "see DESIGN.md section 3" % (nf, fam, time.time() - t0))
+                            "see DESIGN.md section 3" % (nf, " + ".join(fam), time.time() - t0))
     return True
 
 

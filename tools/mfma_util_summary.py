@@ -34,6 +34,7 @@ def main():
         roll = len(targs) > 14 and targs[14] == "true"
         tile = ",".join(targs[:5]) if targs else ""
         key = ("wino_input_kernel (Winograd input transform)" if "wino_input" in n else
+               "conv_planes_w4_kernel (fp16 planes, four-wave 192x128 tile, two workgroups per CU)" if "conv_planes_w4_kernel" in n else
                "conv_planes_kernel<2,128,128,...,WINO> (Winograd GEMM stage)" if wino else
                "conv_planes_kernel<1,256,256,2,4,ROLL> (bf16, 8 waves, 128x64 wave tiles, rolling loop)" if tile == "1,256,256,2,4" else
                "conv_planes_kernel<1,256,128,2,2,ROLL> (bf16, four waves, rolling loop)" if tile == "1,256,128,2,2" and roll else

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's evidence run on one MI355X box: bash tools/round_final.sh TAG   (outputs gpurun_out/TAG_*; see profiles/README.md)
-T=${1:-r04z}
+T=${1:-r05z}
 bash tools/gpu.sh $T tests
 bash tools/gpu.sh $T bench
 bash tools/gpu.sh $T prof "" 64 416

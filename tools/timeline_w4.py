@@ -26,8 +26,11 @@ for name in (sys.argv[1:] or ["c52", "c26", "c104", "L52"]):
         _ffi.check(lib.yv3_conv2d(d, _ffi.stream_ptr()))
     torch.cuda.synchronize()
     a = pc.alpha.cpu()[:32].view(4, 8)
+    a2 = pc.alpha.cpu()[32:40].view(4, 2)
     print(name, "B =", B, "workgroup", WG)
     for w in range(4):
         pro, k0, wait, bar, k1, epi, nk, tot = a[w].tolist()
-        print("  wave %d: prologue %6.0f | per chunk: k-step0 %5.0f  wait %5.0f  barrier %5.0f  k-step1 %5.0f (sum %5.0f; 1152 MFMA cycles) | epilogue %6.0f | chunks %d total %7.0f cycles"
-              % (w, pro, k0, wait, bar, k1, k0 + wait + bar + k1, epi, nk, tot))
+        idx, iss = a2[w].tolist()
+        pro += idx + iss
+        print("  wave %d: prologue %6.0f (index math %5.0f, DMA issue of 2 chunks %5.0f, wait for chunk 0 + its fragments %5.0f) | per chunk: k-step0 %5.0f  wait %5.0f  barrier %5.0f  k-step1 %5.0f (sum %5.0f; 1152 MFMA cycles) | epilogue %6.0f | chunks %d total %7.0f cycles"
+              % (w, pro, idx, iss, pro - idx - iss, k0, wait, bar, k1, k0 + wait + bar + k1, epi, nk, tot))

@@ -40,6 +40,7 @@ for r, idxs in zip(last, groups_of):
     sp, (h, w) = specs[idxs[-1]], hw[idxs[-1]]
     kn = r["Kernel_Name"]
     cfg = ("conv_front (3->32 + 32->64 s2)" if "conv_front" in kn else "conv_res64 (64->32 1x1 + 32->64 3x3 + add)" if "conv_res64" in kn
+           else "w4 192x128 four waves, 2 workgroups/CU " + kn[kn.find("<"):kn.find(">") + 1] if "conv_planes_w4" in kn
            else kn[kn.find("<"):kn.find(">") + 1] if "<" in kn else "conv0")
     key = (sp.cin, sp.cout, sp.k, sp.stride, h, cfg)
     g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl

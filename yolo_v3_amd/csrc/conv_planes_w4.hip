@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_w4_kernel(const ConvParams
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef YV3_TIMELINE          // measurement builds only (-DYV3_MEASURE -DYV3_TIMELINE): cycle split of one workgroup -> alpha[0..31]
     const unsigned long long tl_entry = __builtin_amdgcn_s_memtime();
-    unsigned long long tl_t = tl_entry, tl_pro = 0, tl_k0 = 0, tl_wait = 0, tl_bar = 0, tl_k1 = 0, tl_epi = 0;
+    unsigned long long tl_t = tl_entry, tl_pro = 0, tl_k0 = 0, tl_wait = 0, tl_bar = 0, tl_k1 = 0, tl_epi = 0, tl_idx = 0, tl_iss = 0;
 #define W4_MARK(acc_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - tl_t; tl_t = t_; } while (0)
 #else
 #define W4_MARK(acc_) do {} while (0)
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_w4_kernel(const ConvParams
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    W4_MARK(tl_idx);
     // ---- ring fill: chunks 0 and 1
 #pragma unroll
     for (int d = 0; d < W4_NS; ++d)
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_w4_kernel(const ConvParams
             for (int g = 0; g < W4_G; ++g) dma_piece(g);
         }
 
+    W4_MARK(tl_iss);
     const int l31 = lane & 31, lhi = lane >> 5;
     const int fsw = swz(l31);
     const int x_row = (wm * 96 + l31) * ROWB;                                   // pixel fragments (B operand), block j: + j * 32 rows
@@ -242,6 +244,8 @@ __global__ __launch_bounds__(256, 2) void conv_planes_w4_kernel(const ConvParams
         const float n_ = (float)p.nk;
         dbg[0] = (float)tl_pro; dbg[1] = tl_k0 / n_; dbg[2] = tl_wait / n_; dbg[3] = tl_bar / n_; dbg[4] = tl_k1 / n_; dbg[5] = (float)tl_epi;
         dbg[6] = n_; dbg[7] = (float)(tl_t - tl_entry);
+        float* dbg2 = const_cast<float*>(p.alpha) + 32 + wid * 2;                               // prologue split: index math, DMA issue of two chunks
+        dbg2[0] = (float)tl_idx; dbg2[1] = (float)tl_iss;
     }
 #endif
 }
