@@ -812,6 +812,18 @@ def test_winograd_f32_conv_vs_fp64(cin, cout, B, H, W, res):
     direct = _run_mode(mc, x, mode, r)
     print("fp32 winograd %s: err vs fp64 %.3g (direct kernel %.3g)" % ((cin, cout, B, H, W), e, float(rel_err(direct, ref).max())))
     assert_close_rel(out, direct, 2e-5, "fp32 winograd vs direct")
+    # round 5: the stage's two tiles -- eight waves 128x128 (tune[0] = 9) and four waves 64x128, two workgroups per CU (tune[0] = 8) -- keep
+    # the same K order per accumulator: bit-identical to each other and to the shipped per-launch choice
+    outs = []
+    for code in (9, 8):
+        y2 = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        d2 = engine.make_desc(pc, xg, y2, B, H, W, rg, dtype=mode, wino_ws=ws)
+        d2.options |= _ffi.OPT_WINO_ALWAYS
+        d2.tune[0] = code
+        _ffi.check(_ffi.lib().yv3_conv2d(d2, _ffi.stream_ptr()))
+        outs.append(y2)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], y), "the fp32 Winograd stage's tiles differ"
 
 
 def test_eval_letterbox_and_scale_vs_oracle():

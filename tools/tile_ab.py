@@ -33,7 +33,20 @@ for name in names:
         with torch.no_grad():
             m.conv.weight.zero_()
         pc = engine.pack_conv(m, m._spec(), dt)
-    x = engine.to_planes((torch.rand(B, H, H, cin, device="cuda") - 0.5) * (0.0 if zero else 1.0), dt)
+    hib = int(os.environ.get("HIBITS", "0"))         # energy probe: operands whose fp16 HI part carries only `hib` significant bits (low bits 0),
+                                                     # the LO part a random 11-bit residue below half an ulp of fp16: hi + lo as the kernels see them
+    def sparse_hi(t):
+        if not hib:
+            return t
+        m, e = torch.frexp(t.float())
+        q = torch.ldexp(torch.round(m * (1 << hib)) / (1 << hib), e)                 # `hib` significant bits
+        ulp16 = torch.ldexp(torch.ones_like(q), e - 11)                              # fp16 ulp at this magnitude
+        return q + (torch.rand_like(q) - 0.5) * 0.98 * ulp16                         # |residue| < half an fp16 ulp: RN16(value) == q
+    if hib:
+        with torch.no_grad():
+            m.conv.weight.copy_(sparse_hi(m.conv.weight))
+        pc = engine.pack_conv(m, m._spec(), dt)
+    x = engine.to_planes(sparse_hi(torch.rand(B, H, H, cin, device="cuda") - 0.5) * (0.0 if zero else 1.0), dt)
     r = engine.to_planes((torch.rand(B, ho, wo, cout, device="cuda") - 0.5) * (0.0 if zero else 1.0), dt) if res else None
     fl = 2.0 * B * ho * wo * cout * cin * k * k
     descs, outs = [], []

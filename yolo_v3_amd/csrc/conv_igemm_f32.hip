@@ -116,8 +116,9 @@ __device__ inline void epilogue_lds(const f32x16 (&acc)[MT][NT], const ConvParam
 // WINO: Winograd F(2x2,3x3) GEMM stage (csrc/winograd.hip): the K loop walks the 16 transform positions (Cin/32 chunks each,
 // operand matrix xi * xi_stride into V); at the end of a position the product accumulators are folded into the tile's four
 // outputs with the coefficients of A^T x A^T (0 / +-1: exact) and cleared.
-template <int BM, int BN, int WM, int WN, bool K3, bool DUAL, bool WINO = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const ConvParams p) {
+// MINW: minimum workgroups per CU the register allocation must allow (the four-wave Winograd tile: 2)
+template <int BM, int BN, int WM, int WN, bool K3, bool DUAL, bool WINO = false, int MINW = 1>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_igemm_f32_kernel(const ConvParams p) {
     static_assert(!WINO || (!K3 && !DUAL), "Winograd stage reads a plain tiles x channels matrix per position");
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;      // 32x32 MFMA tiles per wave
@@ -377,11 +378,31 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
     p.H = 1; p.W = (int)T; p.Ho = 1; p.Wo = (int)T; p.M = (int)T; p.stride = 1;
     p.K = 16 * d->cin; p.nk = p.K / BK;
     p.ntiles = d->cout / 128;
-    constexpr int BM = 128, BN = 128, WM = 4, WN = 2;
-    const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
-    const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+    // Round 5: the stage keeps five accumulator sets (216 registers): its 128x128 eight-wave tile runs ONE workgroup per CU, and a launch whose
+    // tiles fill e.g. 1.33 rounds of the chip (256->512 @26x26 bs=64: 340 tiles on 256 CUs) spends a whole second tile time on 84 tiles.  The
+    // same wave tiles (32x64) as a 64x128 tile on FOUR waves, two workgroups per CU (2 x 55 KB of LDS), halve the scheduling quantum: the last
+    // round's half-size tiles spread over more CUs.  Same K order per accumulator: bit-identical.  Chosen when the 128-row tiles leave the last
+    // round at most two thirds full beyond the first round, or fill at most half of the chip (then twice as many CUs work).  Same box,
+    // alternating (tools/wino_f32_tile_ab.py, profiles/r05t_f32_wino_four_wave_tile_ab.txt): 256->512 @26 bs=64 (340 tiles) 0.615 -> 0.515 ms,
+    // 128->256 @52 bs=32 (338) 0.362 -> 0.308, 512->1024 @13 bs=32 (104) 0.549 -> 0.349, @19 bs=16 (104) 0.549 -> 0.349; 200 / 172 / 184 tiles
+    // (0.67-0.78 of a round): 2-3 % slower, kept on the eight-wave tile.  (tune[0] == 8 / 9: force the four-wave / the eight-wave tile.)
+    const long long t128 = ((T + 127) / 128) * p.ntiles;
+    const long long ncu = yv3_num_cu();
+    const long long last = t128 % ncu;
+    const bool half = d->tune[0] == 8 || (d->tune[0] != 9 && ((t128 > ncu && last > 0 && 3 * last <= 2 * ncu) || 2 * t128 <= ncu));
+    if (half) {
+        constexpr int BM = 64, BN = 128, WM = 2, WN = 2;
+        const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
+        const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+        const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true, 2>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+    } else {
+        constexpr int BM = 128, BN = 128, WM = 4, WN = 2;
+        const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
+        const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+        const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+    }
     YV3_CHECK_LAUNCH();
     return 0;
 }
