@@ -513,6 +513,8 @@ def compact_line(out, full_path=None):
     c["config"] = _pick(out.get("config", {}), ("workload", "global_batch", "parallelism", "entry", "collective", "backend"))
     if "lanes" in out:
         c["config"]["lanes"] = out["lanes"]
+    if "stages_ms_one_lane" in out:
+        c["stages_ms_one_lane"] = out["stages_ms_one_lane"]
     if "ok" in out:
         c["ok"] = out["ok"]
     if "roofline" in out:
@@ -736,6 +738,9 @@ def main():
                        if world > 1 else None,
                        "candidates_first_images": cand4, "boxes_kept_first_images": kept4},
             "stages_ms": head["stages_ms"], "stages_note": head["stages_note"], "lanes": lanes_used,
+            # the per-stage split that means what it says: consecutive stages of the ONE-lane pass (under two lanes everything from the
+            # fork to the join is one concurrent section and the later marks are event order, not stage cost)
+            "stages_ms_one_lane": head1["stages_ms"],
             "roofline": dict(head1["roofline"], traffic=None,
                              conv_ms_per_step=st["convs"], avg_launch_ms=round(st["convs"] / n_desc, 5),
                              flop_per_launch_avg=fi / n_desc,

@@ -271,6 +271,11 @@ def concurrent_stream_pair(device, cache=None, tries=6):
     if cache is not None and "stream_pair" in cache:
         return cache["stream_pair"]
     pair = None
+    if not hasattr(torch.cuda, "_sleep"):            # (a torch build without the spin kernel: two fresh streams, unprobed)
+        pair = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        if cache is not None:
+            cache["stream_pair"] = pair
+        return pair
     with torch.cuda.device(device):
         first = torch.cuda.Stream(device=device)
         for _ in range(tries):
