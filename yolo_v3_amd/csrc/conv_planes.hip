@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
     constexpr int BQ = BROWS > RPG ? BROWS / RPG : 1;     // global_load_lds per plane per wave, weight side
     constexpr int G = NP * (AQ + BQ);                     // DMA instructions per chunk per wave
     constexpr int D = NSTAGE - 1;                         // prefetch distance in chunks
-    static_assert((ATAIL == 0 || !PP) && (BROWS <= RPG || BROWS % RPG == 0) && MT >= 1 && NT >= 1, "tile/wave layout");
+    static_assert((BROWS <= RPG || BROWS % RPG == 0) && MT >= 1 && NT >= 1, "tile/wave layout");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef YV3_TIMELINE
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
         };
 #ifdef YV3_TIMELINE
         unsigned long long rl_prep = 0, rl_b0 = 0, rl_wait = 0, rl_bar = 0, rl_b1 = 0, rl_fold = 0, rl_t = __builtin_amdgcn_s_memtime();
+        const unsigned long long rl_t0 = rl_t;       // loop entry (everything before: prologue)
 #define RL_MARK(acc_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - rl_t; rl_t = t_; } while (0)
 #else
 #define RL_MARK(acc_) do {} while (0)
@@ -655,6 +656,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_planes_kernel(const C
                     epilogue_store<NP, BM, BN, WM, WN, false, false, EMTG, true>(yac[o], p, lds, m0, n0, wid, lane, o >> 1, o & 1);
             }
         } else epilogue_store<NP, BM, BN, WM, WN, OUT_F32, true, EMTG>(acc, p, lds, m0, n0, wid, lane);
+#ifdef YV3_TIMELINE
+        if (blockIdx.x == (unsigned)(p.tune[2] > 0 ? p.tune[2] : 100) && lane == 0 && p.alpha && !WINO && NW * 10 <= p.Cout) {   // non-Winograd rolling tiles (bf16): + prologue / epilogue
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            float* dbg = const_cast<float*>(p.alpha) + wid * 10;
+            const float n_ = (float)p.nk;
+            dbg[0] = rl_prep / n_; dbg[1] = rl_b0 / n_; dbg[2] = rl_wait / n_; dbg[3] = rl_bar / n_; dbg[4] = rl_b1 / n_; dbg[5] = n_;
+            dbg[6] = (float)(rl_t0 - tl_entry); dbg[7] = (float)(t_end - rl_t); dbg[8] = (float)(t_end - tl_entry); dbg[9] = 0.f;
+        }
+#endif
         return;
     }
 #ifdef YV3_TIMELINE
@@ -787,7 +797,7 @@ int launch_cfg(const ConvParamsP& p, bool k3, bool dual, bool out_f32, bool use_
     const dim3 sgrid((unsigned)num_cu);
 #define YV3_LAUNCH(K3_, DUAL_, OF_) do { \
     if constexpr (NP == 1 && WM * WN == 8 && NSTAGE >= 3 && !ROLL) { \
-        if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true>), grid, block, lds, s, q); break; } \
+        if (use_pp) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, false, 1, MTG>), grid, block, lds, s, q); break; } \
     } \
     if constexpr (NP == 2 && WM * WN == 8 && NSTAGE >= 3 && !ROLL) { \
         if (use_pp && sk) { hipLaunchKernelGGL((conv_planes_kernel<NP, BM, BN, WM, WN, NSTAGE, K3_, DUAL_, OF_, true, true>), sgrid, block, lds, s, q); break; } \
@@ -1095,6 +1105,12 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         if (np == 1 && force == 9 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 4, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         // (code 11: the 192-row variant of the 256x256 rolling tile -- 96x64 wave tiles; also measured and dropped: 192x128 on four waves
         // and 128x256 on eight, profiles/r04aa_bf16_192row_tiles_ab.log)
+        // (codes 13 / 14: the 256x256 tile with the eight-wave PING-PONG loop, 128x64 wave tiles, 3- / 4-deep ring -- round 5: the rolling tile's waves
+        // leave their barrier together and their fragment reads queue behind each other, ~350 exposed cycles per 1500-cycle chunk, profiles/r05x_*)
+        if (np == 1 && force == 13 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s); }
+        if (np == 1 && force == 14 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 4, 1, 1>(p, k3, dual, out_f32, true, s); }
+        // (code 15: the 192-row variant with the ping-pong loop)
+        if (np == 1 && force == 15 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s); }
         if (np == 1 && force == 11 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         // Round 5: the four-wave 192x128 tile, TWO workgroups per CU (conv_planes_w4.hip): one workgroup's prologue / epilogue / launch gap
@@ -1153,10 +1169,22 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
             // (172 -> 228) +5 %, 128->256 @76x76 bs=16 (361 -> 482) +2.6 %, @76x76 bs=8 +9 % (profiles/r04aa_bf16_192row_tiles_ab.log)
             const long long t192 = ((M + 191) / 192) * (npad / 256);
             const long long r256 = (t256 + ncu - 1) / ncu * ncu, r192 = (t192 + ncu - 1) / ncu * ncu;
+            // Round 5, measured and NOT adopted: the same two tiles with the eight-wave PING-PONG loop (tile codes 13 / 15; tune[1] bit 9 selects it
+            // here).  The rolling tile's eight waves leave their one barrier together, their fragment reads (96 KB per chunk and CU) queue behind
+            // each other and ~350 of a chunk's 1500 cycles are exposed LDS latency (tools/timeline_roll_bf16.py, profiles/r05x_bf16_roll_timeline.txt);
+            // with one four-wave group reading while the other issues MFMAs the layers run bit-identical and +5...+14 % faster IN ISOLATION
+            // (profiles/r05y_bf16_pingpong_*_ab.txt, uniform random operands, 20 back-to-back launches) -- and 3...10 % SLOWER inside the network
+            // (608x608 bs=16: 256->512 @38 980 -> 883 TFLOP/s, step 3.56 -> 3.62 ms; 416x416 bs=64 one-lane conv time 5.12 -> 5.20 ms;
+            // profiles/r05y_bf16_pingpong_in_network_ab.txt).  The rolling loop stays.
+            const bool roll = (p.tune[1] & 512) == 0;
             if (!(p.tune[1] & 16) && t192 * 100 >= 85 * r192 && t256 * 100 < 80 * r256) {
-                p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s);
+                p.ntiles = npad / 256;
+                return roll ? launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s) : launch_cfg<1, 192, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s);
             }
-            if (fill) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
+            if (fill) {
+                p.ntiles = npad / 256;
+                return roll ? launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s) : launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s);
+            }
         }
         if (np == 1 && force == 0 && k3 && blocks256 >= (p.tune[2] > 0 ? p.tune[2] : 256) && !out_f32 && !(p.tune[1] & 8))
             return launch_cfg<1, 256, 128, 2, 2, 3, 2, 2, true>(p, k3, dual, out_f32, false, s);
