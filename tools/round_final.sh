@@ -1,6 +1,7 @@
 #!/bin/bash
 # The round's evidence run on one MI355X box: bash tools/round_final.sh TAG   (outputs gpurun_out/TAG_*; see profiles/README.md)
 T=${1:-r05z}
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 bash tools/gpu.sh $T tests
 bash tools/gpu.sh $T bench
 bash tools/gpu.sh $T prof "" 64 416
