@@ -51,9 +51,12 @@ class conv_bn_relu(nn.Module):
 
     def __init__(self, nin, nout, ks, s=1, pad='SAME', padding=0, bn=True, act="leakyRelu"):
         super().__init__()
+        # The reference's other configurations do not run either: with bn=False its forward calls ``self.bn`` == False (darknet.py:31,43-44:
+        # TypeError), with another `act` there is no ``self.relu`` (AttributeError); only an explicit `padding` with pad != 'SAME' works
+        # there, and nothing in the reference uses it.
         if pad != 'SAME' or not bn or act != "leakyRelu":
-            raise NotImplementedError("only the configuration YoloNet uses is supported "
-                                      "(pad='SAME', bn=True, act='leakyRelu')")
+            raise NotImplementedError("only the configuration YoloNet uses is supported (pad='SAME', bn=True, act='leakyRelu'); "
+                                      "the reference's bn=False / other-act variants fail in its own forward (darknet.py:31,43-44)")
         self.conv = nn.Conv2d(nin, nout, ks, s, (ks - 1) // 2, bias=False)
         self.bn = nn.BatchNorm2d(nout)
         self.relu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
