@@ -486,16 +486,18 @@ def test_conv_bf16_tile_variants_agree_bitwise(cin, cout, s, B, H, W, selected):
     x = engine.to_planes(xn.cuda().permute(0, 2, 3, 1).contiguous(), _ffi.BF16)
     ho, wo = engine.out_hw(H, W, 3, s)
     outs = {}
-    for code in (0, 7, 8, 11, 13, 15, "rule off", "ping-pong loop"):
+    for code in (0, 7, 8, 11, 13, 14, 15, 16, "rule off", "rolling loop", "3-deep ring"):
         y = engine.alloc_act(B, ho, wo, cout, _ffi.BF16, "cuda")
         y.zero_()
         d = engine.make_desc(pc, x, y, B, H, W, None, dtype=_ffi.BF16)
         if code == "rule off":
             d.tune[1] = 16
-        elif code == "ping-pong loop":                  # round 5: the shipped 192x256 / 256x256 tiles with the ping-pong loop (measured, not adopted)
-            d.tune[1] = 512
+        elif code == "rolling loop":                    # round 5: the shipped 192x256 / 256x256 tiles run the ping-pong loop on a 4-deep ring
+            d.tune[1] = 512                             # (bit 9: the round-4 rolling loop; bit 10: ping-pong on the 3-deep ring)
+        elif code == "3-deep ring":
+            d.tune[1] = 1024
         else:
-            d.options = (d.options & ~(0xff << 8)) | (code << 8)      # (13 / 15: the 256- / 192-row tile with the ping-pong loop, forced)
+            d.options = (d.options & ~(0xff << 8)) | (code << 8)      # (13, 14 / 15, 16: the 256- / 192-row tile with the ping-pong loop, 3- / 4-deep ring)
         _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
         outs[code] = y
     torch.cuda.synchronize()

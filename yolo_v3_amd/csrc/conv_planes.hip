@@ -1105,12 +1105,13 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
         if (np == 1 && force == 9 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 4, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         // (code 11: the 192-row variant of the 256x256 rolling tile -- 96x64 wave tiles; also measured and dropped: 192x128 on four waves
         // and 128x256 on eight, profiles/r04aa_bf16_192row_tiles_ab.log)
-        // (codes 13 / 14: the 256x256 tile with the eight-wave PING-PONG loop, 128x64 wave tiles, 3- / 4-deep ring -- round 5: the rolling tile's waves
-        // leave their barrier together and their fragment reads queue behind each other, ~350 exposed cycles per 1500-cycle chunk, profiles/r05x_*)
+        // (codes 13 / 14: the 256x256 tile with the eight-wave PING-PONG loop, 128x64 wave tiles, 3- / 4-deep ring; 14 is what the rule below ships)
         if (np == 1 && force == 13 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s); }
         if (np == 1 && force == 14 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 256, 256, 2, 4, 4, 1, 1>(p, k3, dual, out_f32, true, s); }
         // (code 15: the 192-row variant with the ping-pong loop)
         if (np == 1 && force == 15 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s); }
+        // (code 16: ... with a 4-deep ring: one more chunk of prefetch lead)
+        if (np == 1 && force == 16 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 4, 1, 1>(p, k3, dual, out_f32, true, s); }
         if (np == 1 && force == 11 && npad % 256 == 0 && !out_f32) { p.ntiles = npad / 256; return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s); }
         if (np == 2 && force == 4) { p.ntiles = npad / 64; return launch_cfg<2, 128, 64, 2, 2, 2>(p, k3, dual, out_f32, false, s); }
         // Round 5: the four-wave 192x128 tile, TWO workgroups per CU (conv_planes_w4.hip): one workgroup's prologue / epilogue / launch gap
@@ -1169,21 +1170,25 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
             // (172 -> 228) +5 %, 128->256 @76x76 bs=16 (361 -> 482) +2.6 %, @76x76 bs=8 +9 % (profiles/r04aa_bf16_192row_tiles_ab.log)
             const long long t192 = ((M + 191) / 192) * (npad / 256);
             const long long r256 = (t256 + ncu - 1) / ncu * ncu, r192 = (t192 + ncu - 1) / ncu * ncu;
-            // Round 5, measured and NOT adopted: the same two tiles with the eight-wave PING-PONG loop (tile codes 13 / 15; tune[1] bit 9 selects it
-            // here).  The rolling tile's eight waves leave their one barrier together, their fragment reads (96 KB per chunk and CU) queue behind
-            // each other and ~350 of a chunk's 1500 cycles are exposed LDS latency (tools/timeline_roll_bf16.py, profiles/r05x_bf16_roll_timeline.txt);
-            // with one four-wave group reading while the other issues MFMAs the layers run bit-identical and +5...+14 % faster IN ISOLATION
-            // (profiles/r05y_bf16_pingpong_*_ab.txt, uniform random operands, 20 back-to-back launches) -- and 3...10 % SLOWER inside the network
-            // (608x608 bs=16: 256->512 @38 980 -> 883 TFLOP/s, step 3.56 -> 3.62 ms; 416x416 bs=64 one-lane conv time 5.12 -> 5.20 ms;
-            // profiles/r05y_bf16_pingpong_in_network_ab.txt).  The rolling loop stays.
-            const bool roll = (p.tune[1] & 512) == 0;
+            // Round 5: both tiles run the eight-wave PING-PONG loop on a 4-deep ring instead of the rolling loop (tune[1] bit 9: the rolling loop,
+            // bit 10: ping-pong on the 3-deep ring -- A/B).  The rolling tile's eight waves leave their one barrier together, their fragment
+            // reads (96 KB per chunk and CU) queue behind each other and ~350 of a chunk's 1500 cycles are exposed LDS latency
+            // (tools/timeline_roll_bf16.py, profiles/r05x_bf16_roll_timeline.txt); with one four-wave group reading while the other issues
+            // MFMAs the layers run bit-identical and +5...+14 % faster in isolation, on uniform random operands and on the network's own
+            // activations alike (profiles/r05y_bf16_pingpong_*_ab.txt, r05ad_*).  IN the network the 3-deep ring LOSES 2 % (its DMA lead is one
+            // compute segment, ~1000 cycles: fine for L2-hot repeats of one layer, too short for a layer's first touch of its weights and
+            // inputs); the 4-deep ring gains: conv kernel time 608x608 bs=16 3.17 -> 3.08 ms, 416x416 bs=64 5.21 -> 5.04 ms, step +2 %
+            // (profiles/r05ae_*, r05af_*; a per-layer A/B decides nothing by itself).
+            const bool roll = (p.tune[1] & 512) != 0, pp3 = (p.tune[1] & 1024) != 0;
             if (!(p.tune[1] & 16) && t192 * 100 >= 85 * r192 && t256 * 100 < 80 * r256) {
                 p.ntiles = npad / 256;
-                return roll ? launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s) : launch_cfg<1, 192, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s);
+                if (roll) return launch_cfg<1, 192, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s);
+                return pp3 ? launch_cfg<1, 192, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s) : launch_cfg<1, 192, 256, 2, 4, 4, 1, 1>(p, k3, dual, out_f32, true, s);
             }
             if (fill) {
                 p.ntiles = npad / 256;
-                return roll ? launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s) : launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s);
+                if (roll) return launch_cfg<1, 256, 256, 2, 4, 3, 1, 1, true>(p, k3, dual, out_f32, false, s);
+                return pp3 ? launch_cfg<1, 256, 256, 2, 4, 3, 1, 1>(p, k3, dual, out_f32, true, s) : launch_cfg<1, 256, 256, 2, 4, 4, 1, 1>(p, k3, dual, out_f32, true, s);
             }
         }
         if (np == 1 && force == 0 && k3 && blocks256 >= (p.tune[2] > 0 ? p.tune[2] : 256) && !out_f32 && !(p.tune[1] & 8))
