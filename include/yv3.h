@@ -340,6 +340,12 @@ int yv3_resize_linear(const unsigned char* img_hwc, int H, int W, float* out_chw
 int yv3_correct_boxes(const float* boxes, int B, int cap, int ld, const int* counts, const int* org_wh,
                       int img_w, int img_h, int is_letterbox, int out_xyxy, float* out, void* stream);
 
+/* Stand-alone UpsampleGroup tail (reference darknet.py:159-162: ``F.interpolate(out, scale_factor=2, mode='nearest')`` then
+ * ``torch.cat((out, route_tail), 1)``), NCHW fp32:  out[b, c, y, x] = up[b, c, y/2, x/2] for c < c_up, tail[b, c - c_up, y, x] beyond.
+ * up [B, c_up, h, w], tail [B, c_tail, 2h, 2w], out [B, c_up + c_tail, 2h, 2w].  Pure data movement (bit-exact).  Inside YoloNet
+ * this never runs: the consumer convolution gathers both sources itself (yv3_conv_desc.x / x2 / cin_up). */
+int yv3_upsample2x_concat(const float* up, const float* tail, float* out, int B, int c_up, int c_tail, int h, int w, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU ("yv3_gather_boxes(comm, ...)").  The reference is single-GPU; images are independent
  * (utils.py:152), so the sharded path has exactly ONE exchange: an all-gather of every rank's [b_local, rows, 7] fp32 payload --

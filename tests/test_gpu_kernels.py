@@ -598,6 +598,13 @@ def test_residual_block_and_upsample_concat():
     out = up.cuda()(a.cuda(), t.cuda()).cpu()
     ref = torch.cat((F.interpolate(_ref_cbr(up.conv.cpu(), a).float(), scale_factor=2, mode="nearest"), t), 1)
     assert_close_rel(out, ref, 2e-5, "UpsampleGroup")
+    # ... and its tail (nearest x2 + concat) is ONE HIP launch, bit-exact data movement (round 5; darknet.py:159-162), odd sizes included
+    for (Bq, cu, ct, hq, wq) in ((2, 32, 32, 7, 9), (1, 3, 0, 5, 5), (3, 16, 40, 13, 13)):
+        u, tl = torch.rand(Bq, cu, hq, wq).cuda(), torch.rand(Bq, ct, 2 * hq, 2 * wq).cuda()
+        o = torch.full((Bq, cu + ct, 2 * hq, 2 * wq), float("nan"), device="cuda")
+        _ffi.check(_ffi.lib().yv3_upsample2x_concat(u.data_ptr(), tl.data_ptr(), o.data_ptr(), Bq, cu, ct, hq, wq, _ffi.stream_ptr()))
+        want = torch.cat((F.interpolate(u.cpu(), scale_factor=2, mode="nearest"), tl.cpu()), 1)
+        assert torch.equal(o.cpu(), want)
 
 
 def test_head_conv_255_and_asymmetric_layout():

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "yv3_letterbox": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "yv3_letterbox_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_resize_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "yv3_upsample2x_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_correct_boxes": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "yv3_gather_boxes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "yv3_postproc_cand_bytes": (c_size_t, [c_int, c_int, c_int]),

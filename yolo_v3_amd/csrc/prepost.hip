@@ -200,3 +200,36 @@ extern "C" int yv3_correct_boxes(const float* boxes, int B, int cap, int ld, con
     YV3_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- stand-alone UpsampleGroup tail: nearest x2 of `up` + channel concat with `tail` (reference darknet.py:159-162), NCHW fp32.
+// One thread per output element pair of a row (x even): the two outputs of an upsampled pair share one source element.
+namespace {
+__global__ void upsample2x_concat_kernel(const float* __restrict__ up, const float* __restrict__ tail, float* __restrict__ out,
+                                         int c_up, int c_tail, int h, int w, long long pairs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // over [B][c_up + c_tail][2h][w] (pairs of columns)
+    if (i >= pairs) return;
+    const int W2 = 2 * w, H2 = 2 * h, C = c_up + c_tail;
+    const int xp = (int)(i % w);
+    long long r = i / w;
+    const int y = (int)(r % H2); r /= H2;
+    const int c = (int)(r % C);
+    const long long b = r / C;
+    float2 v;
+    if (c < c_up) {
+        const float s = up[((b * c_up + c) * h + (y >> 1)) * (long long)w + xp];
+        v = make_float2(s, s);
+    } else {
+        v = *reinterpret_cast<const float2*>(tail + ((b * c_tail + (c - c_up)) * H2 + y) * (long long)W2 + 2 * xp);
+    }
+    *reinterpret_cast<float2*>(out + ((b * C + c) * H2 + y) * (long long)W2 + 2 * xp) = v;
+}
+}  // namespace
+
+extern "C" int yv3_upsample2x_concat(const float* up, const float* tail, float* out, int B, int c_up, int c_tail, int h, int w, void* stream) {
+    if (!up || (!tail && c_tail > 0) || !out || B <= 0 || c_up <= 0 || c_tail < 0 || h <= 0 || w <= 0) return YV3_EINVAL;
+    const long long pairs = (long long)B * (c_up + c_tail) * (2 * h) * w;
+    if (pairs > 0x7fffffffLL * 256) return YV3_ESHAPE;
+    hipLaunchKernelGGL(upsample2x_concat_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, up, tail, out, c_up, c_tail, h, w, pairs);
+    YV3_CHECK_LAUNCH();
+    return 0;
+}

@@ -218,10 +218,20 @@ class UpsampleGroup(nn.Module):
 
     def forward(self, route_head, route_tail):
         _ffi.require_cuda(route_head, "route_head")
+        _ffi.require_cuda(route_tail, "route_tail")
         up = self.conv.forward(route_head)
-        # stand-alone use only; inside YoloNet the upsample+concat is fused into the consumer conv
-        up = up.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
-        return torch.cat((up, route_tail), 1)
+        # stand-alone use only (inside YoloNet the upsample + concat is folded into the consumer conv's gather): one HIP launch
+        # (csrc/prepost.hip: yv3_upsample2x_concat), no vendor elementwise ops
+        B, cu, h, w = up.shape
+        tail = route_tail.float().contiguous()
+        if tuple(tail.shape[0:1] + tail.shape[2:]) != (B, 2 * h, 2 * w):
+            raise _ffi.Yv3Error("route_tail must be [B, C, 2h, 2w] for route_head [B, C', h, w]: got %s and %s"
+                                % (tuple(route_tail.shape), tuple(route_head.shape)))
+        out = torch.empty((B, cu + tail.shape[1], 2 * h, 2 * w), device=up.device, dtype=torch.float32)
+        with torch.cuda.device(up.device):
+            _ffi.check(_ffi.lib().yv3_upsample2x_concat(up.data_ptr(), tail.data_ptr(), out.data_ptr(), B, cu, tail.shape[1], h, w,
+                                                        _ffi.stream_ptr()), "yv3_upsample2x_concat")
+        return out
 
 
 class YoloNet(nn.Module):
