@@ -19,7 +19,7 @@ carries the gather); launched under torchrun it requires WORLD_SIZE == --gpus.  
 rendezvous, the product's pack -> gather -> assemble composition and the JSON line on CPU tensors (no GPU, no kernels;
 tests/test_bench_launcher.py).
 
-From 48 images of 416x416 (23 of 608x608) the Detector runs the batch as two sub-batches on two concurrent HIP streams
+From 40 images of 416x416 (19 of 608x608) the Detector runs the batch as two sub-batches on two concurrent HIP streams
 ("lanes": same kernels and bits, each lane runs its own convolutions AND its own filter / NMS, so they fill each
 other's idle CUs; --lanes 1 disables; the automatic lane count is a function of the batch shape, the same on every rank).  --batch is
 images PER GPU (weak scaling, the default), --global-batch fixes the total (strong scaling; BASELINE configs[3] = 256

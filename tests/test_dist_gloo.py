@@ -78,7 +78,7 @@ def _worker(rank, world, port, q):
     # rank-consistent lane count WITHOUT a collective: the automatic choice is a pure function of the batch shape
     import importlib
     ydet = importlib.import_module("yolo_v3_amd.detect")           # (the package exports the FUNCTION detect under that name)
-    ok = ok and ydet.TWO_LANES_MIN_PIXELS == 48 * 416 * 416 and not hasattr(ydet, "_min_over_group")
+    ok = ok and ydet.TWO_LANES_MIN_PIXELS == 40 * 416 * 416 and not hasattr(ydet, "_min_over_group")
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -11,7 +11,7 @@ IOU masks -> scan -> compact, with no host synchronisation until ONE device-to-h
 final ``[B, cap, 7]`` boxes and their counts.  ``Detector`` keeps the buffers (and optionally a
 captured HIP graph of the whole pipeline) alive across calls.
 
-Lanes.  A batch of 48 or more 416 x 416 images (23 at 608 x 608) runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
+Lanes.  A batch of 40 or more 416 x 416 images (19 at 608 x 608) runs as TWO contiguous sub-batches on two HIP streams (``lanes``): the same
 kernels with the same K order -- bit-identical detections on the direct kernels (``net.winograd = False``); with the default
 per-launch choice between the direct and the Winograd form of a 3x3 layer (it depends on the sub-batch's tile count) the two
 schedules agree within fp32 round-off -- but the two launch sequences run concurrently
@@ -34,7 +34,7 @@ from .utils import PostProcessor, boxes_to_list
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
                  max_cand=None, cap=None, dtype=None, graph=False, lanes=None, group=None, sync_lanes=False):
-        """lanes: 1, 2, or None = automatic: 2 from TWO_LANES_MIN_PIXELS (48 images of 416 x 416) upwards when a stream pair that
+        """lanes: 1, 2, or None = automatic: 2 from TWO_LANES_MIN_PIXELS (40 images of 416 x 416) upwards when a stream pair that
         really runs concurrently exists (a deterministic probe, see `concurrent_stream_pair`), else 1 -- a pure function of the
         batch shape, no stopwatch; ``net.lanes`` overrides the default.
         group / sync_lanes: accepted for `ShardedDetector`; the constructor contains NO collective (round 5: the lane count is
@@ -238,11 +238,13 @@ class Detector:
         return self.to_list(bx, host_counts)
 
 
-# Two lanes from this many input pixels per batch (48 images of 416 x 416, 23 of 608 x 608).  Measured, same box, whole pipeline,
+# Two lanes from this many input pixels per batch (40 images of 416 x 416, 19 of 608 x 608).  Round 5, with the four-wave conv tile in the
+# one-lane plans (tools/lanes_threshold_check.sh, profiles/r05ai_two_lanes_threshold_check.txt; bench.py, lanes forced, alternating): 416x416 bs=32
+# -3.5 %, bs=36 -3 %, bs=40 +4 %, bs=48 +4.7 %, bs=56 +9 %; 608x608 bs=16 -4 %, bs=20 (43 equivalents) +2 %, bs=24 +6.6 %.  Earlier, same box, whole pipeline,
 # sustained (profiles/r03y_lane_choice.txt, r03y_lane_choice_order.txt): bs=64 @416 +7 %, 256 images +6 %; bs=32 @416, bs=16 @416,
 # bs=16 @608 (bf16) and the dense bs=8 @608 config: -1...-4 % to +2 % depending on the run -- a wash that a 1 s stopwatch calibration
 # decided differently from box to box.  The rule is the documented threshold; `lanes=` / ``net.lanes`` override it.
-TWO_LANES_MIN_PIXELS = 48 * 416 * 416
+TWO_LANES_MIN_PIXELS = 40 * 416 * 416
 
 
 def streams_run_concurrently(a, b, device):
