@@ -34,7 +34,7 @@ from .utils import PostProcessor, boxes_to_list
 class Detector:
     def __init__(self, net, batch, height, width, obj_conf_thr=0.5, nms_thr=0.4, is_eval=False, use_nms=True,
                  max_cand=None, cap=None, dtype=None, graph=False, lanes=None, group=None, sync_lanes=False):
-        """lanes: 1, 2, or None = automatic: 2 from TWO_LANES_MIN_PIXELS (40 images of 416 x 416) upwards when a stream pair that
+        """lanes: 1, 2, or None = automatic: 2 from `two_lanes_min_pixels(mode)` (default mode: 40 images of 416 x 416; exact fp32 52; BF16 120) upwards when a stream pair that
         really runs concurrently exists (a deterministic probe, see `concurrent_stream_pair`), else 1 -- a pure function of the
         batch shape, no stopwatch; ``net.lanes`` overrides the default.
         group / sync_lanes: accepted for `ShardedDetector`; the constructor contains NO collective (round 5: the lane count is
@@ -63,7 +63,7 @@ class Detector:
             # ONE result tensor + ONE counts buffer ([0:B] candidates, [B:2B] kept) for all lanes: a single D2H copy
             self.boxes = torch.empty((B, self.cap, 7), device=self.device, dtype=torch.float32)
             self.counts = torch.zeros(2 * B, device=self.device, dtype=torch.int32)
-            auto2 = lanes is None and batch >= 2 and batch * height * width >= TWO_LANES_MIN_PIXELS
+            auto2 = lanes is None and batch >= 2 and batch * height * width >= two_lanes_min_pixels(self.engine.dtype)
             if auto2:
                 self._choose_lanes()
             else:
@@ -245,6 +245,15 @@ class Detector:
 # bs=16 @608 (bf16) and the dense bs=8 @608 config: -1...-4 % to +2 % depending on the run -- a wash that a 1 s stopwatch calibration
 # decided differently from box to box.  The rule is the documented threshold; `lanes=` / ``net.lanes`` override it.
 TWO_LANES_MIN_PIXELS = 40 * 416 * 416
+# ... per math mode (images of 416 x 416; same measurement, profiles/r05ai_two_lanes_threshold_check.txt): the default fp16-plane mode and the
+# bf16x3 mode cross over at 40 (f32x3 bs=40 +5 %); exact fp32 at ~52 (bs=48 -0.9 %, bs=56 +2.4 %, bs=64 +6.2 %); BF16 only beyond ~112
+# (bs=64 ONE lane +6.8 %, bs=96 / 112 equal, bs=128 two lanes +3.5 %; 608x608 bs=32 one lane +6 %)
+TWO_LANES_MIN_IMAGES_416 = {_ffi.F32H2: 40, _ffi.F32X3: 40, _ffi.F32: 52, _ffi.BF16: 120}
+
+
+def two_lanes_min_pixels(dtype):
+    """Input pixels per batch from which `Detector` runs two lanes in math mode `dtype` (a pure function of the mode and the batch shape)."""
+    return TWO_LANES_MIN_IMAGES_416.get(dtype, 40) * 416 * 416
 
 
 def streams_run_concurrently(a, b, device):
