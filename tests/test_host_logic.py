@@ -332,3 +332,18 @@ def test_gather_boxes_rejects_bad_arguments_without_touching_rccl():
     assert lib.yv3_gather_boxes(p, p, 0, 1, p, None) == -1
     assert lib.yv3_gather_boxes(None, p, 1, 1, p, None) == -1
     assert b"RCCL" in lib.yv3_error_string(-5)
+
+
+def test_lane_rule_is_a_pure_function_of_mode_and_shape():
+    """Round 5: `Detector`'s automatic lane count has no stopwatch and no collective in it: two lanes from a per-mode number of input pixels
+    (measured crossovers, profiles/r05ai_two_lanes_threshold_check.txt) -- the same answer on every rank of a sharded run."""
+    import importlib
+    d = importlib.import_module("yolo_v3_amd.detect")
+    px = 416 * 416
+    assert d.two_lanes_min_pixels(_ffi.F32H2) == 40 * px == d.TWO_LANES_MIN_PIXELS and d.two_lanes_min_pixels(_ffi.F32X3) == 40 * px
+    assert d.two_lanes_min_pixels(_ffi.F32) == 52 * px and d.two_lanes_min_pixels(_ffi.BF16) == 120 * px
+    for mode, B, size, two in ((_ffi.F32H2, 64, 416, True), (_ffi.F32H2, 36, 416, False), (_ffi.F32H2, 40, 416, True), (_ffi.F32H2, 16, 608, False),
+                               (_ffi.F32H2, 19, 608, True), (_ffi.BF16, 64, 416, False), (_ffi.BF16, 128, 416, True), (_ffi.BF16, 16, 608, False),
+                               (_ffi.F32, 48, 416, False), (_ffi.F32, 64, 416, True)):
+        assert (B * size * size >= d.two_lanes_min_pixels(mode)) == two, (mode, B, size)
+    assert not hasattr(d, "_min_over_group") and "all_reduce" not in open(d.__file__).read()
