@@ -108,6 +108,12 @@ int yv3_conv_front(const float* x_nchw, const float* w0_tap_major, const float* 
 int yv3_conv_front_bf16(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
                         const void* w1_packed, const float* alpha1, const float* beta1, void* y,
                         int B, int H, int W, int* flags, void* stream);
+/* The same for YV3_F32 (exact fp32; csrc/conv_front_f32.hip): the first layer as yv3_conv0(..., YV3_F32) computes it (one fma chain
+ * per output over (c, kh, kw) on the vector ALUs), w1_packed [64][3][3][32] fp32 from yv3_pack_conv_weight(..., YV3_F32),
+ * y fp32 NHWC [B,H/2,W/2,64].  Bit-identical to yv3_conv0 followed by yv3_conv2d in YV3_F32.  H, W multiples of 16 / 32. */
+int yv3_conv_front_f32(const float* x_nchw, const float* w0_tap_major, const float* alpha0, const float* beta0,
+                       const float* w1_packed, const float* alpha1, const float* beta1, float* y,
+                       int B, int H, int W, void* stream);
 
 /* The first residual block in one launch (YV3_F32_F16X2 only): feature.mlist.2 = res_layer(64) (darknet.py:46-53),
  * y = x + conv_bn_relu(32,64,3)(conv_bn_relu(64,32,1)(x)), the 32-channel intermediate kept on chip.  Bit-identical to the two
@@ -122,6 +128,12 @@ int yv3_res_block64(const void* x, const void* w1_packed, const float* alpha1, c
 int yv3_res_block64_bf16(const void* x, const void* w1_packed, const float* alpha1, const float* beta1,
                          const void* w2_packed, const float* alpha2, const float* beta2, void* y,
                          int B, int H, int W, int* flags, void* stream);
+/* The same for YV3_F32 (exact fp32; csrc/conv_res64_f32.hip): x, y fp32 NHWC [B,H,W,64], H a multiple of 8, W of 16 (else
+ * YV3_ESHAPE: run the two launches); w1_packed [32][64], w2_packed [64][3][3][32] from yv3_pack_conv_weight(..., YV3_F32).  Same
+ * products in the same order as the two yv3_conv2d launches in YV3_F32: bit-identical to them. */
+int yv3_res_block64_f32(const float* x, const float* w1_packed, const float* alpha1, const float* beta1,
+                        const float* w2_packed, const float* alpha2, const float* beta2, float* y,
+                        int B, int H, int W, void* stream);
 
 typedef struct yv3_conv_desc {
     const void*  x;         /* NHWC [B,H,W,cin] -- or, when cin_up > 0, the LOW-resolution map

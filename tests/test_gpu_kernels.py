@@ -742,6 +742,68 @@ def test_fused_res64_equals_two_launches_bitwise(B, H, W, mode):
     assert torch.equal(dets[0], dets[1])
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 416, 416), (1, 608, 608), (3, 320, 480), (2, 96, 64), (5, 32, 32)])
+def test_fused_front_f32_equals_two_launches_bitwise(B, H, W):
+    """csrc/conv_front_f32.hip, the exact-fp32 twin of the fused front: feature.mlist.0 + feature.mlist.1 in one launch write BIT FOR BIT
+    what yv3_conv0 (vector-ALU fma chain) followed by yv3_conv2d write in YV3_F32, incl. all four image borders; detections equal."""
+    from yolo_v3_amd import YoloNet, WeightManager
+    stream = synth.weight_stream()
+    net = YoloNet((W, H)).eval()
+    assert WeightManager(net).load_stream(stream) == stream.size
+    net = net.cuda()
+    x = torch.from_numpy(synth.images(B, max(H, W), 10)[:, :, :H, :W].copy()).cuda()
+    net.math_mode = _ffi.F32
+    eng = net.engine(_ffi.F32)
+    outs, dets = [], []
+    for fused in (False, True):
+        eng.fuse_front, eng._plans = fused, {}
+        try:
+            d, plan = eng.forward(x)
+            assert plan.fused_front == fused and plan.first_desc == (3 if fused else 0)
+            if fused:
+                plan.layer_out["feature.mlist.1"].fill_(float("nan"))          # every element must be written
+                d, plan = eng.forward(x)
+            outs.append(plan.layer_out["feature.mlist.1"].clone())
+            dets.append(d.clone())
+        finally:
+            eng.fuse_front, eng._plans = True, {}
+    assert outs[0].shape == (B, H // 2, W // 2, 64) and outs[0].dtype == torch.float32
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1]), "%d elements differ, max |d| %g" % (int((outs[0] != outs[1]).sum()), float((outs[0] - outs[1]).abs().max()))
+    assert torch.equal(dets[0], dets[1])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 416, 416), (1, 608, 608), (3, 320, 480), (2, 96, 64), (5, 32, 32)])
+def test_fused_res64_f32_equals_two_launches_bitwise(B, H, W):
+    """csrc/conv_res64_f32.hip, the exact-fp32 twin: feature.mlist.2 in one launch writes BIT FOR BIT what the two yv3_conv2d
+    launches of YV3_F32 write (same products, same k pairing, same order), incl. all image borders; detections equal."""
+    from yolo_v3_amd import YoloNet, WeightManager
+    stream = synth.weight_stream()
+    net = YoloNet((W, H)).eval()
+    assert WeightManager(net).load_stream(stream) == stream.size
+    net = net.cuda()
+    x = torch.from_numpy(synth.images(B, max(H, W), 9)[:, :, :H, :W].copy()).cuda()
+    net.math_mode = _ffi.F32
+    eng = net.engine(_ffi.F32)
+    outs, mids, dets = [], [], []
+    for fused in (False, True):
+        eng.fuse_res64, eng._plans = fused, {}
+        try:
+            d, plan = eng.forward(x)
+            assert plan.fused_res64 == fused and plan.fused_front and plan.first_desc == (3 if fused else 1)
+            if fused:
+                plan.layer_out["feature.mlist.2.conv2"].fill_(float("nan"))          # every element must be written
+                d, plan = eng.forward(x)
+            outs.append(plan.layer_out["feature.mlist.2.conv2"].clone())
+            dets.append(d.clone())
+        finally:
+            eng.fuse_res64, eng._plans = True, {}
+    assert outs[0].shape == (B, H // 2, W // 2, 64) and outs[0].dtype == torch.float32
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1]), "%d elements differ, max |d| %g" % (int((outs[0] != outs[1]).sum()), float((outs[0] - outs[1]).abs().max()))
+    assert torch.equal(dets[0], dets[1])
+
+
 def _run_wino(m, x_nchw, residual_nchw=None, even=False):
     """conv_bn_relu `m` (3x3, stride 1, on the GPU) through the Winograd F(2x2,3x3) form of the fp16-plane kernel."""
     mode = _ffi.F32H2

@@ -325,10 +325,11 @@ class Plan:
         self.desc_spec = []      # descriptor index -> index into arch.conv_specs (a layer may run as two launches: batch_split)
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         ncu = ncu & ~7 if ncu >= 8 else 256
-        # fp16-plane mode: feature.mlist.0 + feature.mlist.1 run as ONE launch (csrc/conv_front.hip); the first layer's
-        # [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
-        self.fused_front = bool(engine.fuse_front and dt in (F32H2, BF16))
-        # ... and the first residual block (feature.mlist.2: 1x1 64->32 + 3x3 32->64 + add) as one more (csrc/conv_res64.hip)
+        # feature.mlist.0 + feature.mlist.1 run as ONE launch (csrc/conv_front.hip; exact fp32: csrc/conv_front_f32.hip); the first
+        # layer's [B,H,W,32] activation is then never written (conv0_out stays allocated for the un-fused / layer-by-layer paths)
+        self.fused_front = bool(engine.fuse_front and dt in (F32H2, BF16, F32))
+        # ... and the first residual block (feature.mlist.2: 1x1 64->32 + 3x3 32->64 + add) as one more (csrc/conv_res64.hip,
+        # csrc/conv_res64_f32.hip)
         self.fused_res64 = bool(self.fused_front and engine.fuse_res64)
         self.first_desc = 3 if self.fused_res64 else (1 if self.fused_front else 0)
 
@@ -617,6 +618,16 @@ class Engine:
         if not plan.fused_front:
             return self.run_conv0(plan, x)
         p0, p1, d1 = self.packed[0], self.packed[1], plan.descs[0]
+        if self.dtype == F32:
+            _ffi.check(_ffi.lib().yv3_conv_front_f32(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
+                                                     p1.w.data_ptr(), p1.alpha.data_ptr(), p1.beta.data_ptr(), d1.y,
+                                                     plan.B, plan.H, plan.W, _ffi.stream_ptr()), "yv3_conv_front_f32")
+            if plan.fused_res64:
+                p2, p3, d3 = self.packed[2], self.packed[3], plan.descs[2]
+                _ffi.check(_ffi.lib().yv3_res_block64_f32(d1.y, p2.w.data_ptr(), p2.alpha.data_ptr(), p2.beta.data_ptr(),
+                                                          p3.w.data_ptr(), p3.alpha.data_ptr(), p3.beta.data_ptr(), d3.y,
+                                                          plan.B, plan.H // 2, plan.W // 2, _ffi.stream_ptr()), "yv3_res_block64_f32")
+            return
         front = _ffi.lib().yv3_conv_front if self.dtype == F32H2 else _ffi.lib().yv3_conv_front_bf16
         _ffi.check(front(x.data_ptr(), p0.w.data_ptr(), p0.alpha.data_ptr(), p0.beta.data_ptr(),
                                              p1.w.data_ptr(), p1.alpha.data_ptr(), p1.beta.data_ptr(), d1.y,
