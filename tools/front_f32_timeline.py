@@ -1,5 +1,7 @@
 """Barrier-wait vs total cycles of one consumer (matrix-core) and one producer (vector-ALU) wave of conv_front_f32_kernel's workgroup 17
-(debug build with -DYV3_FRONT_TL; YV3_MEASURE=1 YV3_LIB points at it).  416x416, bs from BB (64)."""
+(debug build with -DYV3_FRONT_TL; YV3_MEASURE=1 YV3_LIB points at it).  416x416, bs from BB (64).
+Belongs to the producer / consumer version of the kernel kept as tools/probes/conv_front_f32_specialised_waves.hip.txt (the shipped serial kernel
+has no timeline marks): copy that file over csrc/conv_front_f32.hip, tools/build_variant.sh ftl "-DYV3_FRONT_TL", run this.  profiles/r05t_*."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
