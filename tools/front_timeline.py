@@ -1,13 +1,15 @@
-"""Cycle split of the fused front kernel (debug build with -DYV3_FRONT_TL; YV3_LIB points at it)."""
+"""Cycle split of the fused front kernel (debug build with -DYV3_FRONT_TL; YV3_LIB points at it).  DT=f32h2|bf16, SIZE (416), BB (64)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yolo_v3_amd import YoloNet, WeightManager, synth, _ffi
 torch.cuda.set_device(0)
-net = YoloNet((416, 416)).eval(); WeightManager(net).load_stream(synth.weight_stream()); net = net.cuda()
-eng = net.engine(); eng.ensure_packed()
-plan = eng.plan(64, 416, 416)
-x = torch.rand(64, 3, 416, 416, device="cuda")
+S, B = int(os.environ.get("SIZE", "416")), int(os.environ.get("BB", "64"))
+mode = {"f32h2": _ffi.F32H2, "bf16": _ffi.BF16}[os.environ.get("DT", "f32h2")]
+net = YoloNet((S, S)).eval(); WeightManager(net).load_stream(synth.weight_stream()); net = net.cuda()
+eng = net.engine(mode); eng.ensure_packed()
+plan = eng.plan(B, S, S)
+x = torch.rand(B, 3, S, S, device="cuda")
 for _ in range(3):
     eng.run_front(plan, x)
 torch.cuda.synchronize()

@@ -24,7 +24,7 @@ d=json.loads(sys.stdin.read())
 r=d['roofline']
 print('%s lanes=%d  %.1f img/s  %.3f ms/step  one-lane conv %.3f ms  frac %.4f executed %.4f' % ('$1', d['config']['lanes'], d['value'], d['ms_per_step'], r['conv_ms_per_step'], r['frac'], r.get('executed_frac', 0)))"; }
 case $CMD in
-tests)  timeout 1800 python -m pytest ${@:-tests} -m gpu -x -q -s 2>&1 | tail -150 > $O/${TAG}_tests.log; tail -3 $O/${TAG}_tests.log ;;
+tests)  [ $# -eq 0 ] && set -- tests; timeout 1800 python -m pytest "$@" -m gpu -x -q -s 2>&1 | tail -150 > $O/${TAG}_tests.log; tail -3 $O/${TAG}_tests.log ;;
 bench)  timeout 900 python bench.py "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; cp $O/bench_full.json $O/${TAG}_bench_full.json 2>/dev/null; tail -c 2500 $O/${TAG}_bench.json; tail -3 $O/${TAG}_bench.err ;;
 benchab) LIBS=$1; ENVS=$2; ARGS=$3; R=${4:-2}
         for rep in $(seq $R); do for l in $LIBS; do for e in $ENVS; do

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                 for (int q = 0; q < 8; ++q) {
                     float t0 = fmaf(acc[2 * q], al[2 * q], be[2 * q]), t1 = fmaf(acc[2 * q + 1], al[2 * q + 1], be[2 * q + 1]);
                     t0 = __builtin_fmaxf(t0, 0.1f * t0); t1 = __builtin_fmaxf(t1, 0.1f * t1);
-                    qb[q >> 2][q & 3] = (unsigned)yv3_f2bf(t0) | ((unsigned)yv3_f2bf(t1) << 16);
+                    qb[q >> 2][q & 3] = yv3_pack_bf16x2(t0, t1);
                 }
                 u16* o = y + (((size_t)b * H + gy) * W + gx) * 32 + 8 * lhi;
                 *reinterpret_cast<u32x4v*>(o) = qb[0];

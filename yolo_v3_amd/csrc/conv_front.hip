@@ -262,8 +262,8 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
                         const fh16x2 l = __builtin_convertvector(a - __builtin_convertvector(h, ff32x2), fh16x2);
                         qh[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, h) : 0u;  // outside the image: the second conv's zero padding
                         ql[q >> 2][q & 3] = inimg ? __builtin_bit_cast(unsigned, l) : 0u;
-                    } else {                                                               // bf16, round to nearest even (conv0.hip: yv3_f2bf)
-                        qh[q >> 2][q & 3] = inimg ? ((unsigned)yv3_f2bf(t0) | ((unsigned)yv3_f2bf(t1) << 16)) : 0u;
+                    } else {                                                               // bf16, round to nearest even (as conv0.hip)
+                        qh[q >> 2][q & 3] = inimg ? yv3_pack_bf16x2(t0, t1) : 0u;
                     }
                 }
                 if (gimg[i] >= 0) {

@@ -35,6 +35,13 @@ __host__ __device__ static inline u16 yv3_f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (u16)(u >> 16);
 }
+// two fp32 -> packed bf16 pair, round to nearest even: the hardware conversion (one instruction instead of ~14; same bits as yv3_f2bf for
+// every non-NaN input -- conv_planes_common.h's epilogues use the same instruction)
+__device__ static inline unsigned yv3_pack_bf16x2(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 __host__ __device__ static inline float yv3_bf2f(u16 h) {
     union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16;
     return v.f;
