@@ -334,6 +334,21 @@ def test_gather_boxes_rejects_bad_arguments_without_touching_rccl():
     assert b"RCCL" in lib.yv3_error_string(-5)
 
 
+def test_fused_fp32_entry_points_validate_before_they_launch():
+    """yv3_conv_front_f32 / yv3_res_block64_f32 (round 5): null pointers and non-positive sizes -> YV3_EINVAL, pictures that are not whole
+    8 x 16 tiles -> YV3_ESHAPE ("run the separate launches", include/yv3.h) -- decided before anything touches the GPU (none here)."""
+    lib = _ffi.lib()
+    buf = (ctypes.c_float * 8)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    front = lambda *a: lib.yv3_conv_front_f32(*a)
+    block = lambda *a: lib.yv3_res_block64_f32(*a)
+    ok = (p, p, p, p, p, p, p, p)
+    assert front(*ok, 1, 0, 32, None) == -1 and front(None, p, p, p, p, p, p, p, 1, 32, 32, None) == -1 and front(*ok, 0, 32, 32, None) == -1
+    assert block(*ok, 1, 16, 0, None) == -1 and block(p, p, p, p, p, p, p, None, 1, 16, 16, None) == -1
+    assert front(*ok, 1, 40, 32, None) == -2 and front(*ok, 1, 32, 48, None) == -2            # H % 16, W % 32 (picture coordinates)
+    assert block(*ok, 1, 12, 16, None) == -2 and block(*ok, 1, 16, 24, None) == -2            # H % 8, W % 16 (the block's resolution)
+
+
 def test_lane_rule_is_a_pure_function_of_mode_and_shape():
     """Round 5: `Detector`'s automatic lane count has no stopwatch and no collective in it: two lanes from a per-mode number of input pixels
     (measured crossovers, profiles/r05ai_two_lanes_threshold_check.txt) -- the same answer on every rank of a sharded run."""
