@@ -11,7 +11,7 @@ n = int(os.environ.get("N", "150"))
 stream = synth.weight_stream()
 for mode, B, size, graph in ((_ffi.F32H2, 1, 416, True), (_ffi.F32H2, 2, 416, False), (_ffi.F32H2, 4, 608, False), (_ffi.F32H2, 9, 416, False),
                              (_ffi.F32H2, 9, 416, True), (_ffi.F32H2, 10, 416, False), (_ffi.F32H2, 64, 416, False), (_ffi.BF16, 16, 608, False),
-                             (_ffi.BF16, 8, 608, False), (_ffi.BF16, 64, 416, False), (_ffi.F32, 16, 416, False), (_ffi.F32H2, 16, 416, False), (_ffi.F32H2, 32, 416, False), (_ffi.F32H2, 32, 416, True), (_ffi.F32H2, 16, 608, False), (_ffi.F32H2, 8, 608, False), (_ffi.F32, 32, 416, False), (_ffi.F32, 64, 416, False), (_ffi.F32H2, 128, 416, False)):
+                             (_ffi.BF16, 8, 608, False), (_ffi.BF16, 64, 416, False), (_ffi.F32, 16, 416, False), (_ffi.F32, 64, 416, False), (_ffi.F32, 16, 608, False), (_ffi.F32H2, 16, 416, False), (_ffi.F32H2, 32, 416, False), (_ffi.F32H2, 32, 416, True), (_ffi.F32H2, 16, 608, False), (_ffi.F32H2, 8, 608, False), (_ffi.F32, 32, 416, False), (_ffi.F32, 64, 416, False), (_ffi.F32H2, 128, 416, False)):
     net = load_sw1_net(stream).cuda()
     x = torch.from_numpy(synth.images(min(B, 16), size, 3)).cuda().repeat((B + 15) // 16, 1, 1, 1)[:B].contiguous()
     d = Detector(net, B, size, size, dtype=mode, graph=graph)
