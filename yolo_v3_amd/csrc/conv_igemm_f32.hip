@@ -117,7 +117,8 @@ __device__ inline void epilogue_lds(const f32x16 (&acc)[MT][NT], const ConvParam
 // operand matrix xi * xi_stride into V); at the end of a position the product accumulators are folded into the tile's four
 // outputs with the coefficients of A^T x A^T (0 / +-1: exact) and cleared.
 // MINW: minimum workgroups per CU the register allocation must allow (the four-wave Winograd tile: 2)
-template <int BM, int BN, int WM, int WN, bool K3, bool DUAL, bool WINO = false, int MINW = 1>
+// PIN: the chunk requests stay at the top of the iteration (see there); off under two concurrent lanes
+template <int BM, int BN, int WM, int WN, bool K3, bool DUAL, bool WINO = false, int MINW = 1, bool PIN = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_igemm_f32_kernel(const ConvParams p) {
     static_assert(!WINO || (!K3 && !DUAL), "Winograd stage reads a plain tiles x channels matrix per position");
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
@@ -257,6 +258,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_igemm_f32_kernel(cons
     auto iteration = [&](auto par_, int kc) {
         constexpr int P = decltype(par_)::value;                      // kc & 1
         load_chunk(std::integral_constant<int, P>{}, kc + 2);
+        // PIN: the requests stay HERE.  Left alone, the scheduler sinks them to the end of the iteration to save registers in the 1x1 and
+        // Winograd instantiations, and the next iteration's LDS write then waits (vmcnt 0) for loads issued a few hundred cycles earlier
+        // instead of a whole iteration: 416x416 bs=32 +2.4 %, 608x608 bs=16 +2.4 %, bs=1 +5.6 %, bs=64 on one lane +-0; under TWO lanes
+        // (the other lane's workgroups already fill such gaps, and the stage then holds 250 instead of 228 registers) -1.0 %: not pinned
+        // there (profiles/r05z6_f32_pinned_prefetch_ab.txt).  Scheduling only: same bits.
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         const float* a = As + P * BM * LDS_LD + a_frag;
         const float* b = Bs + P * BN * LDS_LD + b_frag;
 #pragma unroll
@@ -344,16 +351,22 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_igemm_f32_kernel(cons
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch(const ConvParams& p, bool k3, bool dual, hipStream_t s) {
+int launch(const ConvParams& p, bool k3, bool dual, hipStream_t s, bool pin) {
     const int mtiles = (p.M + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
     const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
     const size_t lds = pipe > epi ? pipe : epi;
     const dim3 block(64 * WM * WN);
-    if (k3)        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, lds, s, p);
-    else if (dual) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, lds, s, p);
-    else           hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, lds, s, p);
+    if (pin) {
+        if (k3)        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, false, 1, true>), grid, block, lds, s, p);
+        else if (dual) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, false, 1, true>), grid, block, lds, s, p);
+        else           hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, false, 1, true>), grid, block, lds, s, p);
+    } else {
+        if (k3)        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, lds, s, p);
+        else if (dual) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, lds, s, p);
+        else           hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, lds, s, p);
+    }
     YV3_CHECK_LAUNCH();
     return 0;
 }
@@ -389,19 +402,22 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
     const long long t128 = ((T + 127) / 128) * p.ntiles;
     const long long ncu = yv3_num_cu();
     const long long last = t128 % ncu;
+    const bool pin = !(d->options & YV3_OPT_TWO_LANES);
     const bool half = d->tune[0] == 8 || (d->tune[0] != 9 && ((t128 > ncu && last > 0 && 3 * last <= 2 * ncu) || 2 * t128 <= ncu));
     if (half) {
         constexpr int BM = 64, BN = 128, WM = 2, WN = 2;
         const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
         const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
         const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true, 2>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+        if (pin) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true, 2, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+        else hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true, 2>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
     } else {
         constexpr int BM = 128, BN = 128, WM = 4, WN = 2;
         const dim3 grid((unsigned)(((T + BM - 1) / BM) * p.ntiles));
         const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
         const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+        if (pin) hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true, 1, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
+        else hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(64 * WM * WN), pipe > epi ? pipe : epi, s, p);
     }
     YV3_CHECK_LAUNCH();
     return 0;
@@ -438,6 +454,7 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     p.cchunks = d->cin / BK;
     p.nk = p.K / BK;
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
+    const bool pin = !(d->options & YV3_OPT_TWO_LANES);           // (see PIN)
     if (yv3_conv2d_f32_form(d) == 1) return launch_wino_f32(d, p, s);
 
     // Tile selection: widest N tile the layer fills; for launches that would leave most of the
@@ -446,15 +463,15 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     if (np % 128 == 0) {
         const long long blocks128 = ((M + 127) / 128) * (np / 128);
         // (tune[0]: kernel-selection override for A/B measurements -- 6 four-wave 128x128, 2 64x64 tiles)
-        if (blocks128 >= 384 && d->tune[0] == 6) { p.ntiles = np / 128; return launch<128, 128, 2, 2>(p, k3, dual, s); }
+        if (blocks128 >= 384 && d->tune[0] == 6) { p.ntiles = np / 128; return launch<128, 128, 2, 2>(p, k3, dual, s, pin); }
         // eight waves (4 x 2 of 32x64) per 128x128 tile, two workgroups per CU: four waves per SIMD hide each other's fragment
         // reads / barriers better than two (13x13 3x3 layer at bs=64: 80 -> 102 TFLOP/s, whole network +5 %)
         // 1x1 layers (K <= 1024: 8-32 chunks per tile) run better on 64x64 tiles, four workgroups per CU: 512->256 @26x26 at bs=64
         // 82 -> 103 TFLOP/s, 256->128 @52x52 95 -> 98 (tune[0] == 7: 128x128 tiles for them too)
-        if (blocks128 >= 384 && d->tune[0] != 2 && (k3 || d->tune[0] == 7)) { p.ntiles = np / 128; return launch<128, 128, 4, 2>(p, k3, dual, s); }
-        p.ntiles = np / 64; return launch<64, 64, 2, 2>(p, k3, dual, s);
+        if (blocks128 >= 384 && d->tune[0] != 2 && (k3 || d->tune[0] == 7)) { p.ntiles = np / 128; return launch<128, 128, 4, 2>(p, k3, dual, s, pin); }
+        p.ntiles = np / 64; return launch<64, 64, 2, 2>(p, k3, dual, s, pin);
     }
-    if (np % 64 == 0) { p.ntiles = np / 64; return launch<128, 64, 2, 2>(p, k3, dual, s); }
+    if (np % 64 == 0) { p.ntiles = np / 64; return launch<128, 64, 2, 2>(p, k3, dual, s, pin); }
     p.ntiles = np / 32;
-    return launch<128, 32, 4, 1>(p, k3, dual, s);
+    return launch<128, 32, 4, 1>(p, k3, dual, s, pin);
 }
