@@ -208,6 +208,16 @@ typedef struct yv3_conv_desc {
     const float* alpha_wino;
     void*        wino_ws;
     size_t       wino_ws_bytes;
+    /* Winograd F(4x4,3x3) path of the YV3_F32 kernels (k = 3, stride 1, cin_up = 0, cout % 64 == 0; csrc/conv_wino4_f32.hip): when
+       w_wino4 is not NULL the layer may run as  V = B^T d B over 6x6 input patches at stride 4 (points 0, 1, -1, 1/2, -2, inf; fp32;
+       written to wino_ws as [36][T][cin], T = B*ceil(H/4)*ceil(W/4): yv3_wino4_workspace_bytes)  ->  thirty-six T x cout x cin GEMMs on
+       v_mfma_f32_16x16x4_f32, folded on the fly into the sixteen outputs of every tile: 4x fewer matrix instructions than the direct
+       form, 1.78x fewer than F(2x2,3x3).  w_wino4 = yv3_pack_wino4_weight_f32 of U = G g G^T; scale / shift = alpha / beta.  Results
+       differ from the direct kernel by fp32 round-off (whole network: within 1.4x of the direct form's distance from an fp64
+       evaluation on hostile data, equal on the headline data -- tools/winograd_f32_gate.py).  The library takes this form when its
+       64-channel x 32-tile workgroups fill the chip (yv3_conv2d_form == YV3_FORM_WINOGRAD4), else F(2x2) by w_wino's rule, else the
+       direct kernel. */
+    const void*  w_wino4;
 } yv3_conv_desc;
 
 #define YV3_OPT_NO_PINGPONG 1u    /* fp16-plane 8-wave tiles: single-phase main loop instead of the two-group ping-pong */
@@ -225,6 +235,12 @@ size_t yv3_conv_workspace_bytes(void);
 /* Size of yv3_conv_desc.wino_ws for a B x H x W x cin input (YV3_F32_F16X2). */
 size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin);
 
+/* Size of yv3_conv_desc.wino_ws that the F(4x4,3x3) form of a YV3_F32 layer needs (never more than yv3_wino_workspace_bytes for
+ * H, W >= 4).  U [cout][cin][6][6] fp32 = G g G^T (points 0, 1, -1, 1/2, -2, inf; computed by the caller, in fp64 and rounded once)
+ * -> the GEMM stage's packed image of cout*cin*36 floats; cout % 64 == 0, cin % 32 == 0. */
+size_t yv3_wino4_workspace_bytes(int B, int H, int W, int cin);
+int yv3_pack_wino4_weight_f32(const float* u_oc66, float* packed, int cout, int cin, void* stream);
+
 /* y = act(conv(x) * alpha + beta) (+ residual), implicit GEMM on the MFMA units. */
 int yv3_conv2d(const yv3_conv_desc* desc, void* stream);
 
@@ -235,6 +251,7 @@ int yv3_conv2d(const yv3_conv_desc* desc, void* stream);
  * bench.py (executed vs algorithmic FLOPs). */
 #define YV3_FORM_DIRECT   0
 #define YV3_FORM_WINOGRAD 1
+#define YV3_FORM_WINOGRAD4 2     /* YV3_F32: F(4x4,3x3), 36 multiplications per 4x4 outputs and channel pair (4x fewer than direct) */
 int yv3_conv2d_form(const yv3_conv_desc* desc);
 
 /* Run `n` convolutions back to back on `stream` (one host call for a whole network plan). */

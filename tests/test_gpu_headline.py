@@ -48,16 +48,17 @@ def headline(sw1_sd):
 
 
 def _form_counts(plan):
-    """{(cin, cout, k, stride, Hout): [launches, of which Winograd]} of one plan's launch sequence."""
+    """{(cin, cout, k, stride, Hout): [launches, of which Winograd (either form), of which F(4x4,3x3)]} of one plan's launch sequence."""
     specs = arch.conv_specs()
     hw = arch.conv_output_hw(plan.H)
     out = {}
     for si, f in plan.forms():
         sp = specs[si]
         key = (sp.cin, sp.cout, sp.k, sp.stride, hw[si][0])
-        c = out.setdefault(key, [0, 0])
+        c = out.setdefault(key, [0, 0, 0])
         c[0] += 1
-        c[1] += f
+        c[1] += f != 0
+        c[2] += f == 2
     return out
 
 
@@ -120,14 +121,17 @@ def test_small_batch_default_plan_vs_oracle(sw1_stream, sw1_sd, headline, B, siz
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["unmatched_frac"] <= 0.005, d
 
 
-@pytest.mark.parametrize("mode,n_wino", [(_ffi.F32H2, 18), (_ffi.F32, 31)])
-def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mode, n_wino):
+@pytest.mark.parametrize("mode,n_wino,f4", [(_ffi.F32H2, 18, False), (_ffi.F32, 31, False), (_ffi.F32, 31, True)])
+def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mode, n_wino, f4):
     """``net.winograd = "always"`` (YV3_OPT_WINO_ALWAYS on every descriptor): ALL eligible layers -- 18 in the fp16-plane mode
     (cin >= 256), 31 in the exact-fp32 mode (cin >= 64) -- in the Winograd form at a batch size whose tile counts would
     otherwise select the direct kernels for most of them; 32 images (BASELINE configs[1]'s batch) vs the oracle, plus the
-    reference's own golden boxes for the dog image."""
+    reference's own golden boxes for the dog image.  Exact-fp32 mode: once with every eligible layer in F(2x2,3x3)
+    (``net.winograd4 = False``) and once with every one in F(4x4,3x3) (round 6, csrc/conv_wino4_f32.hip; 13x13, 26x26 pictures hang
+    over the 4x4 tile grid)."""
     net = load_sw1_net(sw1_stream).cuda()
     net.winograd = "always"
+    net.winograd4 = f4
     net.math_mode = mode
     x = torch.from_numpy(synth.images(32, 416, 1))
     with torch.no_grad():
@@ -136,12 +140,13 @@ def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mod
     plan = net.engine().plan(32, 416, 416)
     fc = _form_counts(plan)
     assert sum(v[1] for v in fc.values()) == n_wino, fc
+    assert sum(v[2] for v in fc.values()) == (n_wino if f4 else 0), fc
     assert all(v[1] in (0, v[0]) for v in fc.values())
     err = assert_close_rel(got, ref, TOL, "forced-Winograd detections mode %d" % mode)
     want = oc.postprocess(ref, 80, 0.5, 0.4)
     res = detect(net, x.cuda(), 80, 0.5, 0.4)
     d = boxes_delta(res, want, 32)
-    print("forced Winograd mode %d: %d Winograd launches, max det err %.3g; boxes %s" % (mode, n_wino, err, d))
+    print("forced Winograd mode %d (F(4x4) %s): %d Winograd launches, max det err %.3g; boxes %s" % (mode, f4, n_wino, err, d))
     print("forced Winograd mode %d: unmatched_frac %.5f (bound 0.002)" % (mode, d["unmatched_frac"]))
     assert d["ref_boxes"] > 300 and d["unmatched_frac"] <= 0.002, d
     assert d["max_rel_err_coords"] <= TOL and d["max_abs_err_conf"] <= TOL and d["max_abs_err_score"] <= TOL
@@ -150,7 +155,7 @@ def test_whole_net_forced_winograd_vs_oracle(sw1_stream, sw1_sd, golden_dir, mod
     dog = torch.from_numpy(g["dog_u8"].astype(np.float32) / np.float32(255.0)).permute(2, 0, 1).unsqueeze(0).contiguous().cuda()
     with torch.no_grad():
         dets = net.forward_cat(dog)
-    assert sum(f for _, f in net.engine().plan(1, 416, 416).forms()) == n_wino
+    assert sum(f != 0 for _, f in net.engine().plan(1, 416, 416).forms()) == n_wino
     e_dog = assert_close_rel(dets[:, g["dog416_rows"]].cpu(), g["dog416_dets_rows"], TOL, "dog image, forced Winograd")
     fused = detect(net, dog, 80, 0.5, 0.4)
     assert len(fused) == int(g["dog416_nres"][0])
@@ -210,14 +215,14 @@ def test_form_query_mirrors_the_launch_dispatch(sw1_stream, monkeypatch):
     net.winograd = "always"
     net.engine().ensure_packed()
     plan = net.engine().plan(4, 416, 416)
-    assert sum(f for _, f in plan.forms()) == 0
+    assert sum(f != 0 for _, f in plan.forms()) == 0
     monkeypatch.delenv("YV3_K3S1")
     net2 = load_sw1_net(sw1_stream).cuda()
     net2.winograd = "always"
     net2.engine().ensure_packed()
     plan2 = net2.engine().plan(4, 416, 416)
     forms = plan2.forms()
-    assert sum(f for _, f in forms) == 18
+    assert sum(f != 0 for _, f in forms) == 18
     lib = _ffi.lib()
     j = plan2.first_desc + [f for _, f in forms].index(1)
     d = type(plan2.descs[j])()

@@ -869,8 +869,8 @@ def test_winograd_f32_conv_vs_fp64(cin, cout, B, H, W, res):
     ref = _ref_cbr(m, x) + (r.double() if res else 0)
     mc = m.cuda()
     sp = mc._spec()
-    pc = engine.pack_conv(mc, sp, mode, winograd=True)
-    assert pc.w_wino is not None
+    pc = engine.pack_conv(mc, sp, mode, winograd=True, winograd4=False)
+    assert pc.w_wino is not None and pc.w_wino4 is None
     xg = x.cuda().permute(0, 2, 3, 1).contiguous()
     rg = r.cuda().permute(0, 2, 3, 1).contiguous() if res else None
     y = torch.full((B, H, W, cout), float("nan"), device="cuda")
@@ -897,6 +897,53 @@ def test_winograd_f32_conv_vs_fp64(cin, cout, B, H, W, res):
         outs.append(y2)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], y), "the fp32 Winograd stage's tiles differ"
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W,res", [(64, 128, 2, 20, 28, True), (128, 256, 2, 13, 13, True), (256, 512, 3, 26, 26, False),
+                                                (512, 1024, 2, 13, 13, True), (256, 128, 1, 7, 5, True), (128, 256, 3, 52, 52, True),
+                                                (64, 64, 1, 4, 4, False), (128, 192, 5, 19, 19, True), (256, 512, 40, 13, 13, True),
+                                                (128, 256, 1, 1, 9, True), (96, 128, 2, 6, 3, False)])
+def test_winograd4_f32_conv_vs_fp64(cin, cout, B, H, W, res):
+    """fp32-MFMA mode (YV3_F32): the Winograd F(4x4,3x3) form (csrc/conv_wino4_f32.hip; points 0, 1, -1, 1/2, -2, inf) of
+    conv_bn_relu(3x3, s1) (+ residual): pictures whose sides are and are not multiples of 4 (13, 19, 26, 7x5, 1x9: the last tile row / column
+    hangs over the edge by 1-3 pixels), tile counts that are not multiples of the workgroup's 32 (M tails), 64-wide channel blocks, 3 chunks per
+    position (cin 96), every output written exactly once (NaN-filled buffer).  Against fp64: 3e-5 * max(1,|ref|) (direct kernel: 2e-5; the form's
+    transforms add ~1.5x, tools/winograd_f32_gate.py), against the direct fp32 kernel and the F(2x2) form: 3e-5.  The form query must say 2."""
+    mode = _ffi.F32
+    m = _rand_cbr(cin, cout, 3, 1, seed=cin + cout + H)
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.rand(B, cin, H, W, generator=g) * 2 - 0.5
+    r = (torch.rand(B, cout, H, W, generator=g) - 0.5) if res else None
+    ref = _ref_cbr(m, x) + (r.double() if res else 0)
+    mc = m.cuda()
+    sp = mc._spec()
+    pc = engine.pack_conv(mc, sp, mode, winograd=True) if cout % 128 == 0 else None
+    if pc is None:                       # (engine.wino_eligible asks for cout % 128 -- the F(2x2) stage's tile; the F(4x4) image needs cout % 64)
+        pc = engine.pack_conv(mc, sp, mode)
+        pc.w_wino4 = engine.pack_wino4(mc.conv.weight.detach().float().contiguous(), sp)
+    assert pc.w_wino4 is not None
+    xg = x.cuda().permute(0, 2, 3, 1).contiguous()
+    rg = r.cuda().permute(0, 2, 3, 1).contiguous() if res else None
+    y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    ws = torch.zeros(max(_ffi.lib().yv3_wino_workspace_bytes(B, H, W, cin), _ffi.lib().yv3_wino4_workspace_bytes(B, H, W, cin)), dtype=torch.uint8, device="cuda")
+    d = engine.make_desc(pc, xg, y, B, H, W, rg, dtype=mode, wino_ws=ws)
+    if not d.w_wino4:                    # (make_desc binds the Winograd pointers for layers that carry w_wino)
+        d.w_wino4 = pc.w_wino4.data_ptr(); d.wino_ws = ws.data_ptr(); d.wino_ws_bytes = ws.numel()
+    d.options |= _ffi.OPT_WINO_ALWAYS
+    assert _ffi.lib().yv3_conv2d_form(d) == 2
+    _ffi.check(_ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()))
+    out = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(out).all(), "an output element was not written"
+    e = assert_close_rel(out, ref, 3e-5, "fp32 winograd F(4x4) conv %s" % ((cin, cout, H, W),))
+    direct = _run_mode(mc, x, mode, r)
+    print("fp32 winograd F(4x4) %s: err vs fp64 %.3g (direct kernel %.3g)" % ((cin, cout, B, H, W), e, float(rel_err(direct, ref).max())))
+    assert_close_rel(out, direct, 3e-5, "fp32 winograd F(4x4) vs direct")
+    # too small a workspace is an error, not a crash; tune[0] == 10 opts the descriptor out of the form
+    d.wino_ws_bytes = _ffi.lib().yv3_wino4_workspace_bytes(B, H, W, cin) - 4
+    assert _ffi.lib().yv3_conv2d(d, _ffi.stream_ptr()) == -3
+    d.wino_ws_bytes = ws.numel()
+    d.tune[0] = 10
+    assert _ffi.lib().yv3_conv2d_form(d) != 2
 
 
 def test_eval_letterbox_and_scale_vs_oracle():

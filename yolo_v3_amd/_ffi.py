@@ -31,13 +31,16 @@ class ConvDesc(ctypes.Structure):
                 ("dec_out", c_void_p), ("dec_out_batch_stride", c_longlong), ("dec_stride", c_float),
                 ("dec_anchors", c_float * 6), ("options", ctypes.c_uint), ("big_tile_min", c_int), ("tune", c_int * 4),
                 ("x_plane_stride", c_longlong), ("x2_plane_stride", c_longlong), ("y_plane_stride", c_longlong),
-                ("w_wino", c_void_p), ("alpha_wino", c_void_p), ("wino_ws", c_void_p), ("wino_ws_bytes", ctypes.c_size_t)]
+                ("w_wino", c_void_p), ("alpha_wino", c_void_p), ("wino_ws", c_void_p), ("wino_ws_bytes", ctypes.c_size_t),
+                ("w_wino4", c_void_p)]
 
 
 _SIGNATURES = {
     "yv3_version": (c_int, []),
     "yv3_conv_workspace_bytes": (ctypes.c_size_t, []),
     "yv3_wino_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    "yv3_wino4_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    "yv3_pack_wino4_weight_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "yv3_error_string": (ctypes.c_char_p, [c_int]),
     "yv3_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "yv3_fold_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),

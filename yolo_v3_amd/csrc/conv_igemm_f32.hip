@@ -423,7 +423,10 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
     return 0;
 }
 
-// Does this fp32 descriptor take the Winograd F(2x2,3x3) form?  (exported through yv3_conv2d_form)
+int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s);
+long long yv3_wino4_f32_workgroups(const yv3_conv_desc* d);
+
+// Which form does this fp32 descriptor take: direct (0), Winograd F(2x2,3x3) (1) or F(4x4,3x3) (2)?  (exported through yv3_conv2d_form)
 int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
     {   // the shape error yv3_conv2d_f32 reports before it launches anything (the form query returns what the launch would)
@@ -431,11 +434,19 @@ int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
         const long long Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
         if ((long long)d->B * Ho * Wo > 0x7fffffffLL) return YV3_ESHAPE;
     }
+    // F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer matrix instructions than direct.  Its workgroups are 64 channels x 32 tiles of 4x4 pixels,
+    // two per CU: taken when they fill at least half of those slots (tune[0] == 10: never, 11: whenever the filters are there)
+    if (d->w_wino4 && d->wino_ws && k3 && d->stride == 1 && !dual && d->cout % 64 == 0 && d->cout_pad == d->cout && d->alpha && d->tune[0] != 10) {
+        if ((d->options & YV3_OPT_WINO_ALWAYS) || d->tune[0] == 11 || yv3_wino4_f32_workgroups(d) >= yv3_num_cu())
+            return d->wino_ws_bytes < yv3_wino4_workspace_bytes(d->B, d->H, d->W, d->cin) ? YV3_EWORKSPACE : YV3_FORM_WINOGRAD4;
+    }
     if (!(d->w_wino && d->alpha_wino && k3 && d->stride == 1 && !dual && d->cout % 128 == 0 && d->cout_pad == d->cout)) return 0;
     // fp32 MFMA runs at the vector rate, so this layer is matrix-bound whatever its shape: Winograd whenever the 128x128 tiles
     // (a quarter of the direct kernel's rows) still fill a good part of the chip, or YV3_OPT_WINO_ALWAYS
-    const long long tiles = (((long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) + 127) / 128) * (d->cout / 128);
-    return ((d->options & YV3_OPT_WINO_ALWAYS) || tiles * 100 >= 40 * yv3_num_cu()) ? 1 : 0;
+    const long long T2 = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+    const long long tiles = ((T2 + 127) / 128) * (d->cout / 128);
+    if (!((d->options & YV3_OPT_WINO_ALWAYS) || tiles * 100 >= 40 * yv3_num_cu())) return 0;
+    return (!d->wino_ws || d->wino_ws_bytes < (size_t)16 * T2 * d->cin * sizeof(float)) ? YV3_EWORKSPACE : YV3_FORM_WINOGRAD;
 }
 
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
@@ -455,7 +466,10 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     p.nk = p.K / BK;
     const bool k3 = d->k == 3, dual = d->cin_up > 0;
     const bool pin = !(d->options & YV3_OPT_TWO_LANES);           // (see PIN)
-    if (yv3_conv2d_f32_form(d) == 1) return launch_wino_f32(d, p, s);
+    const int form = yv3_conv2d_f32_form(d);
+    if (form < 0) return form;
+    if (form == YV3_FORM_WINOGRAD4) return yv3_conv2d_wino4_f32(d, s);
+    if (form == YV3_FORM_WINOGRAD) return launch_wino_f32(d, p, s);
 
     // Tile selection: widest N tile the layer fills; for launches that would leave most of the
     // 256 CUs idle (small batch at 13x13 / 26x26) fall back to 64x64 tiles for 4x the blocks.

@@ -64,11 +64,12 @@ class StreamKTimeout(_ffi.Yv3Error):
 
 class PackedConv:
     """Device-side parameters of one convolution in kernel layout."""
-    __slots__ = ("spec", "w", "alpha", "beta", "cout_pad", "w_wino", "alpha_wino")
+    __slots__ = ("spec", "w", "alpha", "beta", "cout_pad", "w_wino", "alpha_wino", "w_wino4")
 
-    def __init__(self, spec, w, alpha, beta, cout_pad, w_wino=None, alpha_wino=None):
+    def __init__(self, spec, w, alpha, beta, cout_pad, w_wino=None, alpha_wino=None, w_wino4=None):
         self.spec, self.w, self.alpha, self.beta, self.cout_pad = spec, w, alpha, beta, cout_pad
-        self.w_wino, self.alpha_wino = w_wino, alpha_wino      # Winograd-domain filters of an eligible 3x3 layer (F32H2)
+        self.w_wino, self.alpha_wino = w_wino, alpha_wino      # Winograd-domain filters of an eligible 3x3 layer (F32H2, F32)
+        self.w_wino4 = w_wino4                                 # F(4x4,3x3) filters (exact-fp32 mode, csrc/conv_wino4_f32.hip)
 
 
 def conv_params(module):
@@ -132,7 +133,29 @@ def pack_wino(weight_f32, alpha_bn, spec, cout_pad, dtype=F32H2):
     return wp, alpha_w
 
 
-def pack_conv(module, spec, dtype, winograd=False):
+# F(4x4,3x3) with the Toom-Cook points (0, 1, -1, 1/2, -2, inf): G [6][3] (csrc/conv_wino4_f32.hip holds B^T and A^T; the point set is the
+# one whose whole-network error equals the direct form's, tools/winograd_f32_gate.py)
+_WINO4_G = ((1.0, 0.0, 0.0), (1.0 / 3, 1.0 / 3, 1.0 / 3), (-1.0 / 3, 1.0 / 3, -1.0 / 3),
+            (-16.0 / 15, -8.0 / 15, -4.0 / 15), (1.0 / 15, -2.0 / 15, 4.0 / 15), (0.0, 0.0, 1.0))
+
+
+def wino4_filters(weight_f32):
+    """U = G g G^T [O,C,6,6] of a 3x3 filter bank: fp64 elementwise torch ops (no vendor GEMM), rounded to fp32 once."""
+    g64 = weight_f32.double()
+    t = torch.stack([sum(_WINO4_G[i][j] * g64[:, :, j, :] for j in range(3) if _WINO4_G[i][j] != 0.0) for i in range(6)], 2)      # [O,C,6,3]
+    U = torch.stack([sum(_WINO4_G[l][k] * t[:, :, :, k] for k in range(3) if _WINO4_G[l][k] != 0.0) for l in range(6)], 3)        # [O,C,6,6]
+    return U.float().contiguous()
+
+
+def pack_wino4(weight_f32, spec):
+    """The exact-fp32 mode's F(4x4,3x3) filter image (yv3_pack_wino4_weight_f32); scale / shift stay the layer's alpha / beta."""
+    U = wino4_filters(weight_f32)
+    wp = torch.empty(spec.cout * spec.cin * 36, device=weight_f32.device, dtype=torch.float32)
+    _ffi.check(_ffi.lib().yv3_pack_wino4_weight_f32(U.data_ptr(), wp.data_ptr(), spec.cout, spec.cin, _ffi.stream_ptr()), "yv3_pack_wino4_weight_f32")
+    return wp
+
+
+def pack_conv(module, spec, dtype, winograd=False, winograd4=True):
     """Pack one conv (+BN) for the HIP kernels.  Parameters must already be on the GPU."""
     lib = _ffi.lib()
     weight, bn, bias = conv_params(module)
@@ -173,7 +196,8 @@ def pack_conv(module, spec, dtype, winograd=False):
                                         cout_pad, dtype, s), "yv3_pack_conv_weight")
     if winograd and wino_eligible(spec, dtype):
         ww, aw = pack_wino(w_orig, alpha_bn, spec, cout_pad, dtype)
-        return PackedConv(spec, wp, alpha, beta, cout_pad, ww, aw)
+        w4 = pack_wino4(w_orig, spec) if (dtype == F32 and winograd4 and spec.cout % 64 == 0 and cout_pad == spec.cout) else None
+        return PackedConv(spec, wp, alpha, beta, cout_pad, ww, aw, w4)
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
 
@@ -246,6 +270,8 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
     if wino_ws is not None and pc.w_wino is not None and batch is None and dtype in (F32H2, F32) and (out_dtype is None or out_dtype == dtype):
         d.w_wino, d.alpha_wino = _ptr(pc.w_wino), _ptr(pc.alpha_wino)
         d.wino_ws, d.wino_ws_bytes = _ptr(wino_ws), wino_ws.numel() * wino_ws.element_size()
+        if dtype == F32 and pc.w_wino4 is not None:
+            d.w_wino4 = _ptr(pc.w_wino4)
     if batch is not None:
         b0, nb = batch
         ho, wo = out_hw(H, W, sp.k, sp.stride)
@@ -311,6 +337,8 @@ class Plan:
             # eligible layers read 64 channels at H/4 (F32 only), 128 at H/8, 256 at H/16, 512 at H/32: the shallowest one is the largest
             lo = WINO_MIN_CIN_F32 if dt == F32 else WINO_MIN_CIN
             need = max(wsb(B, H // f, W // f, c) for c, f in ((64, 4), (128, 8), (256, 16), (512, 32)) if c >= min(lo, 512))
+            if dt == F32:          # (the F(4x4) form's V is 36 positions x a sixteenth of the pixels: never the larger one, asked for the record)
+                need = max(need, max(_ffi.lib().yv3_wino4_workspace_bytes(B, H // f, W // f, c) for c, f in ((64, 4), (128, 8), (256, 16), (512, 32))))
             self.wino_ws = torch.zeros(need, device=dev, dtype=torch.uint8)       # (zero-filled: hand-over flags of the even schedule)
 
         def buf(h, w, c, dtype=dt):
@@ -430,7 +458,8 @@ class Plan:
 
     def forms(self):
         """Per descriptor of the launch sequence (``descs[first_desc:]``): (conv spec index, form) with form = 0 direct /
-        1 Winograd, as the library decides it on the current device (``yv3_conv2d_form``: tile count, lane count, CU count)."""
+        1 Winograd F(2x2,3x3) / 2 Winograd F(4x4,3x3) (exact-fp32 mode), as the library decides it on the current device
+        (``yv3_conv2d_form``: tile count, lane count, CU count)."""
         lib = _ffi.lib()
         out = []
         for j in range(self.first_desc, self.n_desc):
@@ -443,11 +472,17 @@ class Plan:
     def executed_mac_factor(self):
         """{conv spec index: matrix multiplications executed / direct-form multiplications} for the launch sequence:
         16/36 for a launch that takes the Winograd F(2x2,3x3) form (even pictures; the tile grid of an odd picture is
-        ceil(H/2) x ceil(W/2), so e.g. 13x13 executes 16 * 49 per 9 * 169 direct), 1 otherwise."""
+        ceil(H/2) x ceil(W/2), so e.g. 13x13 executes 16 * 49 per 9 * 169 direct), 36/144 for F(4x4,3x3) (13x13: 36 * 16 per
+        9 * 169), 1 otherwise."""
         out = {}
         for j, (si, f) in zip(range(self.first_desc, self.n_desc), self.forms()):
             d = self.descs[j]
-            out[si] = (16.0 * ((d.H + 1) // 2) * ((d.W + 1) // 2)) / (9.0 * d.H * d.W) if f == 1 else 1.0
+            if f == 1:
+                out[si] = (16.0 * ((d.H + 1) // 2) * ((d.W + 1) // 2)) / (9.0 * d.H * d.W)
+            elif f == 2:                # F(4x4,3x3): 36 per 4x4 tile instead of 144 (tile grid ceil(H/4) x ceil(W/4))
+                out[si] = (36.0 * ((d.H + 3) // 4) * ((d.W + 3) // 4)) / (9.0 * d.H * d.W)
+            else:
+                out[si] = 1.0
         return out
 
 
@@ -489,6 +524,8 @@ class Engine:
             wino = "always" if env == "always" else env != "0"
         self.wino_always = wino == "always" or bool(measure_env("YV3_WINO_ALWAYS"))
         self.winograd = bool(wino)
+        # exact-fp32 mode: F(4x4,3x3) (csrc/conv_wino4_f32.hip) wherever the library's rule takes it; net.winograd4 = False keeps F(2x2,3x3)
+        self.winograd4 = bool(getattr(net, "winograd4", measure_env("YV3_WINO4", "1") != "0"))
         # net.deterministic = True: ONE switch for "the same image gives the same bits at every batch size, batch position and lane
         # count": direct one-tile-per-workgroup kernels only (no per-launch Winograd choice, no stream-K split tiles); `Detector`
         # then also runs a single lane.  Costs ~10 % at bs=64.
@@ -579,7 +616,7 @@ class Engine:
         _ffi.require_cuda(first, "YoloNet parameters (call net.cuda() first)")
         self.device = first.device
         with torch.cuda.device(self.device):
-            self.packed = [pack_conv(self.net.get_submodule(sp.name), sp, self.dtype, self.winograd) for sp in self.specs]
+            self.packed = [pack_conv(self.net.get_submodule(sp.name), sp, self.dtype, self.winograd, self.winograd4) for sp in self.specs]
         self._sig = sig
         self._plans = {}
         self.generation += 1          # holders of a Plan (Detector) must rebuild: descriptors point into `packed`
