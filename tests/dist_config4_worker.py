@@ -24,20 +24,24 @@ from yolo_v3_amd import synth, detect, detect_sharded, YoloNet, WeightManager, d
 from oracle.boxdelta import boxes_delta                                                        # noqa: E402
 
 
-def make_net(stream, deterministic):
+def make_net(stream, deterministic, shared_gpu):
     net = YoloNet((416, 416)).eval()
     assert WeightManager(net).load_stream(stream) == stream.size
     net = net.cuda()
-    net.lanes = 1                  # eight processes share one GPU: no lane calibration against each other
+    if shared_gpu:
+        net.lanes = 1              # several processes share one GPU: no second lane against each other
     if deterministic:
         net.deterministic = True
     return net
 
 
 def main():
+    """Two ways to run: (a) 8 ranks over gloo on ONE GPU (test_config4_full_size_8_ranks_equals_single_gpu); (b) one rank per GPU
+    over RCCL on a box with >= 2 GPUs (tests/test_gpu_dist.py::test_rccl_multi_gpu_sharded_equals_single_gpu, self-arming)."""
     rank, local, world = ydist.init_from_env()
-    assert world == 8 and dist.get_backend() == "gloo"
-    torch.cuda.set_device(0)
+    rccl = dist.get_backend() == "nccl"
+    assert (rccl and world <= torch.cuda.device_count()) or (not rccl and world == 8)
+    torch.cuda.set_device(local if rccl else 0)
     stream = synth.weight_stream()
     x = torch.from_numpy(synth.images(64, 416, 3)).repeat(4, 1, 1, 1)          # 256 images on the host (64 distinct scenes x 4)
     x = x + torch.arange(256, dtype=torch.float32).view(256, 1, 1, 1) * (1.0 / 4096.0)   # ... made distinct: no two images equal
@@ -47,30 +51,40 @@ def main():
     calls = []
     orig = dist.all_gather_into_tensor
     dist.all_gather_into_tensor = lambda *a, **k: (calls.append(tuple(a[1].shape)), orig(*a, **k))[1]
-    net_d = make_net(stream, True)
+    net_d = make_net(stream, True, not rccl)
     with torch.no_grad():
         got_d = detect_sharded(net_d, x)                       # warm (builds the sharded detector: no collective beyond the gather at lanes=1)
         calls.clear()
         got_d = detect_sharded(net_d, x)
     per_call = len(calls)
     shapes = list(calls)
-    net = make_net(stream, False)
+    net = make_net(stream, False, not rccl)
     with torch.no_grad():
         got = detect_sharded(net, x)
+    lanes_here = [sd.det.lanes for sd in net.__dict__.get("_sharded_detectors", {}).values()]
     dist.all_gather_into_tensor = orig
     assert len(got_d) == len(got) == 256
-    dist.barrier()
+    lanes_all = [None] * world
+    dist.all_gather_object(lanes_all, lanes_here)              # (after the measured calls: which lane count every rank chose)
+    if rccl:
+        dist.barrier(device_ids=[local])
+    else:
+        dist.barrier()
     if rank == 0:
         with torch.no_grad():
             want = detect(net_d, x.cuda())                     # one GPU, all 256 images, same deterministic kernels
         assert len(want) == 256
         equal = sum(1 for a, b in zip(got_d, want) if tuple(a.shape) == tuple(b.shape) and torch.equal(a, b))
         d = boxes_delta(got, want, 256)
-        print(json.dumps({"world": world, "images": 256, "shard": hi - lo, "collectives_per_call": per_call, "payload": shapes,
+        print(json.dumps({"world": world, "backend": dist.get_backend(), "lanes": lanes_all,
+                          "images": 256, "shard": hi - lo, "collectives_per_call": per_call, "payload": shapes,
                           "bitwise_equal_images": equal, "boxes": int(sum(b.shape[0] for b in want if b.numel())),
                           "default_mode_unmatched_frac": round(d["unmatched_frac"], 6),
                           "default_mode_max_rel_err_coords": float("%.3g" % d["max_rel_err_coords"])}))
-    dist.barrier()
+    if rccl:
+        dist.barrier(device_ids=[local])
+    else:
+        dist.barrier()
     dist.destroy_process_group()
 
 

@@ -271,8 +271,11 @@ def test_hostile_conv_level_all_fp32_modes(cin, cout, k, s, B, H, W):
 def test_forward_cannot_return_saturated_values(sw1_stream):
     """YoloNet.forward in the default mode checks the kernels' saturation flag for the SAME call: a single ``net(x)``,
     ``forward_cat`` or eval-mode ``detect`` on a network whose activations leave +-65504 raises instead of returning
-    clamped values; ``net.async_forward = True`` defers the check to the next call (documented opt-out)."""
+    clamped values; ``net.async_forward = True`` defers the check to the next call (documented opt-out).  (The strict form,
+    ``net.strict_range = True``; since round 6 the default re-runs the batch in F32X3 instead:
+    tests/test_gpu_e2e.py::test_fp16_plane_overflow_falls_back_to_bf16x3.)"""
     net = load_sw1_net(sw1_stream).cuda()
+    net.strict_range = True
     x = torch.from_numpy(synth.images(1, 416, 3)).cuda()
     net(x, None)
     with torch.no_grad():

@@ -100,6 +100,35 @@ def test_bench_two_ranks_on_this_gpu_over_gloo():
     assert [r_["lanes"] for r_ in out["ranks"]] == [1, 1]
 
 
+def test_rccl_multi_gpu_sharded_equals_single_gpu():
+    """SELF-ARMING: on a box with >= 2 GPUs -- the driver's scaling node; the build's own boxes have one -- spawn
+    one rank per GPU (up to 8) over RCCL and run BASELINE configs[3] (416x416, global batch 256, contiguous shards) through
+    ``detect_sharded``: every image bit-identical to the single-GPU ``detect`` under ``net.deterministic``, the default-mode result within
+    the set-wise tolerance, exactly ONE collective per call, and the SAME lane count on every rank.  Skipped on one GPU, where
+    tests/test_gpu_headline.py::test_config4_full_size_8_ranks_equals_single_gpu runs the same worker as 8 gloo ranks."""
+    import json
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d): the N > 1 RCCL path is exercised by the driver's multi-GPU node" % n)
+    world = max(w for w in (2, 4, 8) if w <= n)                  # 256 images divide evenly
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "YV3_DIST_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "tests", "dist_config4_worker.py")]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("config 4 over RCCL, %d GPUs:" % world, out)
+    assert out["world"] == world and out["backend"] == "nccl" and out["images"] == 256 and out["shard"] == 256 // world
+    assert out["collectives_per_call"] == 1 and out["bitwise_equal_images"] == 256 and out["boxes"] > 2000
+    assert out["default_mode_unmatched_frac"] <= 0.002
+    assert len(out["lanes"]) == world and all(l == out["lanes"][0] for l in out["lanes"]), out["lanes"]
+
+
 def test_yv3_gather_boxes_is_one_rccl_allgather():
     """The C entry point of the path's one exchange (include/yv3.h: yv3_gather_boxes) on a communicator the CALLER owns:
     a world-1 ncclComm_t made with RCCL's own API (ctypes on the librccl torch ships), the payload `pack_payload` builds, one

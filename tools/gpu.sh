@@ -13,9 +13,11 @@
 #   pmc    "bench args" DTYPE SIZE B NLAUNCH  three --pmc passes (MFMA busy / FETCH / WRITE)       -> TAG_mfma_util.json, TAG_traffic_*.json
 #   plan   "B.." SIZE DTYPE                   which kernel / tile / form runs which layer, per batch size (kernel trace)  -> TAG_plan_table.txt
 #   probe  NAME                               tools/probes/NAME (a hipcc-built micro-benchmark)    -> TAG_NAME.txt
-export YV3_MEASURE=1        # tuning / A-B environment overrides (YV3_TUNE, YV3_TILE, YV3_LIB, ...) are honoured in measurement sessions only
 export TMPDIR=/tmp
 TAG=$1; CMD=$2; shift 2
+# tuning / A-B environment overrides (YV3_TUNE, YV3_TILE, YV3_LIB, ...) are honoured in measurement sessions only: the A/B commands set
+# YV3_MEASURE=1; `tests`, `bench`, `prof`, `pmc`, `plan` run the product as shipped with every stray YV3_* variable removed
+case $CMD in benchab|tool|probe) export YV3_MEASURE=1 ;; *) for v in $(env | grep -o '^YV3_[A-Z0-9_]*' | grep -v '^YV3_DUMP_PLAN$'); do unset $v; done ;; esac
 O=gpurun_out; mkdir -p $O
 uselib() { if [ "$1" = base ]; then unset YV3_LIB; else export YV3_LIB=$PWD/yolo_v3_amd/libyv3_$1.so; fi; }
 line() { python -c "

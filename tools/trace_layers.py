@@ -6,12 +6,12 @@ from yolo_v3_amd import arch
 path, B, size = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-NAMES = ("conv_igemm", "conv0_", "conv_planes", "conv_front", "conv_res64")
+NAMES = ("conv_igemm", "conv_wino4", "conv0_", "conv_planes", "conv_front", "conv_res64")
 convs = []
 pending = None                      # a Winograd layer = wino_input_kernel + the WINO conv_planes launch: one entry, durations added
 for r in rows:
     kn = r["Kernel_Name"]
-    if "wino_input_kernel" in kn:
+    if "wino_input_kernel" in kn or "wino_input_f32_kernel" in kn or "wino4_input_f32_kernel" in kn:       # (the input transform of the layer's form)
         pending = r
         continue
     if any(n in kn for n in NAMES):
@@ -19,6 +19,7 @@ for r in rows:
             r = dict(r)
             r["End_Timestamp"] = str(int(r["End_Timestamp"]) + int(pending["End_Timestamp"]) - int(pending["Start_Timestamp"]))
             r["Kernel_Name"] = kn.replace("conv_planes_kernel<", "winograd+conv_planes_kernel<")
+            r["xform_ns"] = int(pending["End_Timestamp"]) - int(pending["Start_Timestamp"])
             pending = None
         convs.append(r)
 fused_front = any("conv_front" in r["Kernel_Name"] for r in convs)      # feature.mlist.0 + .1 in one launch
@@ -41,11 +42,12 @@ for r, idxs in zip(last, groups_of):
     kn = r["Kernel_Name"]
     cfg = ("conv_front (3->32 + 32->64 s2)" if "conv_front" in kn else "conv_res64 (64->32 1x1 + 32->64 3x3 + add)" if "conv_res64" in kn
            else "w4 192x128 four waves, 2 workgroups/CU " + kn[kn.find("<"):kn.find(">") + 1] if "conv_planes_w4" in kn
-           else kn[kn.find("<"):kn.find(">") + 1] if "<" in kn else "conv0")
+           else "F(4x4) 64x32 four waves, 2 workgroups/CU (+ input transform)" if "conv_wino4" in kn
+           else kn[kn.find("<"):kn.find(">") + 1] + (" (+ input transform)" if "xform_ns" in r else "") if "<" in kn else "conv0")
     key = (sp.cin, sp.cout, sp.k, sp.stride, h, cfg)
-    g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
+    g = groups.setdefault(key, [0, 0.0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl; g[3] += r.get("xform_ns", 0) * 1e-9 if isinstance(r, dict) else 0.0
     tot += dur; totf += fl
 print("%-44s %3s %9s %8s %7s" % ("cin,cout,k,s,H,tile", "n", "ms total", "ms each", "TF"))
-for key, (n, dur, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
-    print("%-44s %3d %9.3f %8.3f %7.1f" % (str(key), n, dur * 1e3, dur * 1e3 / n, fl / dur / 1e12))
+for key, (n, dur, fl, xf) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+    print("%-44s %3d %9.3f %8.3f %7.1f%s" % (str(key), n, dur * 1e3, dur * 1e3 / n, fl / dur / 1e12, "   (input transform %.3f ms each)" % (xf * 1e3 / n) if xf else ""))
 print("total conv kernel time %.3f ms, %.1f TF" % (tot * 1e3, totf / tot / 1e12))

@@ -60,4 +60,7 @@ for name in sys.argv[1:] or ["c52", "c26", "c13", "c104"]:
     fl = 2.0 * B * H * H * cout * cin * 9
     print("%-4s B=%d %dx%d %d->%d:" % (name, B, H, H, cin, cout) +
           "".join("  %s (form %d): %.4f ms %.0f alg TF, err %.2e" % (v[0], f, t, fl / t / 1e9, e) for v, t, f, e in zip(variants, best, forms, errs)))
+    if os.environ.get("TL"):            # measurement builds with -DW4F_TIMELINE=<workgroup>: per wave [sync, burst, fold] ticks per chunk, loop ticks, epilogue ticks, chunks
+        _ffi.check(lib.yv3_conv2d(descs[2], st)); torch.cuda.synchronize()
+        print("     timeline (s_memtime ticks, 100 MHz): " + "  ".join("w%d %s" % (w, ["%.1f" % v for v in ys[2].view(-1)[w * 8:w * 8 + 6].tolist()]) for w in range(4)))
     sys.stdout.flush()

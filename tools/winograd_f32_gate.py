@@ -8,8 +8,8 @@ V = B^T d B in fp32, M = sum_c U V accumulated in fp32, Y = A^T M A in fp32 -- a
   * decoded detections against the fp32 oracle (what the parity tests assert, bar 1e-4);
   * final boxes (boxes_delta) against the fp32 oracle's.
 
-Forms: direct (= the oracle), F(2x2) (shipped), F(4x4) with the Lavin points (0, +-1, +-2, inf), and F(4x4) with the
-points (0, +-1, +-1/2, inf) that the literature finds more accurate.   Data: SW-1 on synthetic scenes (the headline data) and
+Forms: direct (= the oracle), F(2x2), F(4x4) with the SHIPPED points (0, 1, -1, 1/2, -2, inf), with the Lavin points
+(0, +-1, +-2, inf) and with (0, +-1, +-1/2, inf), the latter two also restricted to the high-resolution layers.   Data: SW-1 on synthetic scenes (the headline data) and
 the hostile calibrated set (tests/helpers.hostile_state_dict).   python tools/winograd_f32_gate.py [n_images]
 """
 import os
@@ -139,7 +139,8 @@ if __name__ == "__main__":
     f2 = cook_toom([0, 1, -1], m=2); check_matrices(*f2, m=2)
     f4 = cook_toom([0, 1, -1, 2, -2]); check_matrices(*f4)
     f4h = cook_toom([0, 1, -1, 0.5, -0.5]); check_matrices(*f4h)
-    forms = [("direct", None), ("F(2x2) shipped", (f2, 2)), ("F(4x4) 0,+-1,+-2", (f4, 4)), ("F(4x4) 0,+-1,+-1/2", (f4h, 4)),
+    f4s = cook_toom([0, 1, -1, 0.5, -2]); check_matrices(*f4s)          # the SHIPPED points (csrc/conv_wino4_f32.hip)
+    forms = [("direct", None), ("F(2x2)", (f2, 2)), ("F(4x4) 0,1,-1,1/2,-2 SHIPPED", (f4s, 4)), ("F(4x4) 0,+-1,+-2", (f4, 4)), ("F(4x4) 0,+-1,+-1/2", (f4h, 4)),
              ("F(4x4) H>=48, else F(2x2)", (f4, 4, 48, (f2, 2))), ("F(4x4) H>=24, else F(2x2)", (f4, 4, 24, (f2, 2))),
              ("F(4x4)+-1/2 H>=48, else F2", (f4h, 4, 48, (f2, 2))), ("F(4x4)+-1/2 H>=24, else F2", (f4h, 4, 24, (f2, 2)))]
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.stream_to_state_dict(synth.weight_stream()).items()}

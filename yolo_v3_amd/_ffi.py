@@ -11,6 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YV3_LIB (another build of the library: A/B variants, the -DYV3_MEASURE build) is honoured in measurement sessions only (YV3_MEASURE=1)
 LIB_PATH = (os.environ.get("YV3_LIB") if os.environ.get("YV3_MEASURE") == "1" else None) or os.path.join(_HERE, "libyv3.so")
 
+if os.environ.get("YV3_MEASURE") != "1":
+    _stray = sorted(k for k in os.environ if k.startswith("YV3_") and k not in ("YV3_MEASURE", "YV3_DIST_BACKEND", "YV3_DUMP_PLAN"))
+    if _stray:                      # (a user who points YV3_LIB at another build must learn that it is not loaded)
+        import warnings
+        warnings.warn("yolo_v3_amd: %s set but ignored -- library / kernel-selection overrides are honoured in measurement sessions only "
+                      "(YV3_MEASURE=1); the bundled libyv3.so and the default plans are used" % ", ".join(_stray), RuntimeWarning)
+
 F32, BF16, F32X3, F32H2 = 0, 1, 2, 3
 ACT_LINEAR, ACT_LEAKY = 0, 1
 PP_EVAL, PP_PROB = 1, 2

@@ -46,8 +46,26 @@ constexpr int ROWB = 128;                      // bytes per LDS row: one 32-chan
 constexpr int U_BYTES = BNC * ROWB;            // 8 KB
 constexpr int V_BYTES = BMT * ROWB;            // 4 KB
 constexpr int STAGE = U_BYTES + V_BYTES;       // 12 KB
-constexpr int NSTAGE = 3;
-constexpr int EP_LD = BNC + 4;                 // floats per row of the epilogue's transpose tile
+#ifndef W4F_NSTAGE
+#define W4F_NSTAGE 3
+#endif
+#ifndef W4F_PRIO
+#define W4F_PRIO 3                              // s_setprio(1) around a chunk's MFMAs: +2 % on the launches' time in the network (profiles/r06i_*)
+#endif
+#ifndef W4F_EXTRA_LDS
+#define W4F_EXTRA_LDS 0                         // (measurement builds: pad the allocation to force one workgroup per CU)
+#endif
+#ifndef W4F_DMA_FIRST
+#define W4F_DMA_FIRST 0                         // (1: the chunk's three requests right behind the barrier -- A/B builds)
+#endif
+constexpr int NSTAGE = W4F_NSTAGE;             // ring stages: requests run NSTAGE chunks ahead of the multiplication
+// measurement builds only (-DYV3_MEASURE -DW4F_ABL=mask; results INVALID): 1 no epilogue, 2 no MFMAs, 4 no fragment reads, 8 no DMA,
+// 16 no barrier, 32 no fold
+#if defined(YV3_MEASURE) && defined(W4F_ABL)
+constexpr int ABL = W4F_ABL;
+#else
+constexpr int ABL = 0;
+#endif
 
 struct Wino4Params {
     const float* v;          // [36][T][C]
@@ -163,11 +181,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
     const float* vsrc = p.v + (long long)vt * p.C + (((lane & 7) ^ w4f_swz(vrow)) << 2);
     int pf_c = 0;                                                         // channel offset of the chunk being requested
     int pf_k = 0;                                                         // its chunk number
-    auto dma_chunk = [&](unsigned char* stage) {
-        __builtin_amdgcn_global_load_lds(W4F_GPTR(usrc), W4F_LPTR(stage + (2 * wid) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(W4F_GPTR(usrc + 256), W4F_LPTR(stage + (2 * wid + 1) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(W4F_GPTR(vsrc + pf_c), W4F_LPTR(stage + U_BYTES + wid * 1024), 16, 0, 0);
-        // advance -- past the last chunk the requests repeat it (a constant number of requests per iteration keeps the vmcnt waits exact)
+    // one chunk = three 1 KB pieces per wave; `dma_piece(i, stage)` requests piece i, `dma_advance()` moves on to the next chunk --
+    // past the last chunk the requests repeat it (a constant number of requests per iteration keeps the vmcnt waits exact)
+    auto dma_piece = [&](int i, unsigned char* stage) {
+        if (ABL & 8) return;
+        if (i == 0)      __builtin_amdgcn_global_load_lds(W4F_GPTR(usrc), W4F_LPTR(stage + (2 * wid) * 1024), 16, 0, 0);
+        else if (i == 1) __builtin_amdgcn_global_load_lds(W4F_GPTR(usrc + 256), W4F_LPTR(stage + (2 * wid + 1) * 1024), 16, 0, 0);
+        else             __builtin_amdgcn_global_load_lds(W4F_GPTR(vsrc + pf_c), W4F_LPTR(stage + U_BYTES + wid * 1024), 16, 0, 0);
+    };
+    auto dma_advance = [&]() {
         if (pf_k + 1 < nk) {
             ++pf_k;
             usrc += BNC * 32;
@@ -201,43 +223,101 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
         }
     }
 
-    unsigned char* st0 = lds;
-    unsigned char* st1 = lds + STAGE;
-    unsigned char* st2 = lds + 2 * STAGE;
-    dma_chunk(st0);
-    dma_chunk(st1);
+    // ring fill: chunks 0 .. NSTAGE-1
+#pragma unroll
+    for (int d = 0; d < NSTAGE; ++d) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma_piece(i, lds + d * STAGE);
+        dma_advance();
+    }
+    // the fragments of the chunk being multiplied live in registers (F); the NEXT chunk's are read while its MFMAs run
+    struct Frag { f32x4 ua, va0, va1, ub, vb0, vb1; };
+    auto read_frag = [&](const unsigned char* st) {
+        Frag f;
+        if (ABL & 4) { f.ua = f.va0 = f.va1 = f.ub = f.vb0 = f.vb1 = f32x4{(float)lane, 1.f, 2.f, 3.f}; return f; }
+        f.ua = *reinterpret_cast<const f32x4*>(st + u_off0);
+        f.va0 = *reinterpret_cast<const f32x4*>(st + v_off0[0]);
+        f.va1 = *reinterpret_cast<const f32x4*>(st + v_off0[1]);
+        f.ub = *reinterpret_cast<const f32x4*>(st + u_off1);
+        f.vb0 = *reinterpret_cast<const f32x4*>(st + v_off1[0]);
+        f.vb1 = *reinterpret_cast<const f32x4*>(st + v_off1[1]);
+        return f;
+    };
+    w4f_wait_vmcnt<3 * (NSTAGE - 1)>();
+    __builtin_amdgcn_s_barrier();
+#if W4F_PRIO == 1                                          // static priority for one of a SIMD's two waves (by its hardware wave slot)
+    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(2);
+#elif W4F_PRIO == 2                                        // ... by dispatch round
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2);
+#endif
+    Frag F0 = read_frag(lds), F1;
+    int s_cur = 0;                                         // stage of the chunk whose fragments are in registers
+    using TrueT = std::integral_constant<bool, true>;
+    using FalseT = std::integral_constant<bool, false>;   // (host: cin % 64 == 0 -> an even number of chunks per position)
 
-    // one chunk: [wait for my pieces of it] [barrier: everybody's pieces are there, everybody has left the stage two chunks back]
-    // [request the chunk two ahead into that stage] [6 fragment reads] [16 MFMAs]
-    auto chunk = [&]() {
-        w4f_wait_vmcnt<3>();
-        __builtin_amdgcn_s_barrier();
+    // one chunk (its fragments already in registers): [wait for my pieces of the NEXT chunk] [barrier: the next chunk is complete, and
+    // everybody has taken this chunk's fragments out of its stage] [request chunk + NSTAGE into that stage, read the next chunk's
+    // fragments: both under this chunk's 16 MFMAs -- a request costs its wave 60-250 cycles of issue, a fragment read ~100 of latency
+    // (DESIGN.md section 5); in front of the MFMAs they were half of the loop's time (profiles/r06e_wino4_ablations.txt)]
+    // (F: this chunk's fragments, G: where the next chunk's go -- the caller alternates two register sets, so nothing is copied)
+#if defined(YV3_MEASURE) && defined(W4F_TIMELINE)          // cycle split of one workgroup's main loop -> the first floats of y (results INVALID)
+    unsigned long long tl_t = __builtin_amdgcn_s_memtime(), tl_sync = 0, tl_burst = 0, tl_fold = 0;
+    const unsigned long long tl_entry = tl_t;
+#define W4F_MARK(acc_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - tl_t; tl_t = t_; } while (0)
+#else
+#define W4F_MARK(acc_) do {} while (0)
+#endif
+    // FIRST: the first chunk of a transform position -- its first MFMAs start from a zero accumulator (an inline constant: the product
+    // blocks are never cleared by vector instructions, which cost a wave ~30 cycles each while its SIMD's other wave issues MFMAs)
+    auto chunk = [&](auto first_c, const Frag& F, Frag& G) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        W4F_MARK(tl_fold);
+        w4f_wait_vmcnt<3 * (NSTAGE - 2)>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): my fragment reads of THIS chunk (issued a chunk ago) are out of its stage
+        if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        dma_chunk(st2);
-        const f32x4 ua = *reinterpret_cast<const f32x4*>(st0 + u_off0);
-        const f32x4 va0 = *reinterpret_cast<const f32x4*>(st0 + v_off0[0]);
-        const f32x4 va1 = *reinterpret_cast<const f32x4*>(st0 + v_off0[1]);
-        const f32x4 ub = *reinterpret_cast<const f32x4*>(st0 + u_off1);
-        const f32x4 vb0 = *reinterpret_cast<const f32x4*>(st0 + v_off1[0]);
-        const f32x4 vb1 = *reinterpret_cast<const f32x4*>(st0 + v_off1[1]);
+        W4F_MARK(tl_sync);
+        unsigned char* const fr_ = lds + s_cur * STAGE;
+        s_cur = s_cur + 1 == NSTAGE ? 0 : s_cur + 1;
+        G = read_frag(lds + s_cur * STAGE);
+#if W4F_PRIO == 3
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            P[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], va0[t], P[0], 0, 0, 0);
-            P[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], va1[t], P[1], 0, 0, 0);
+            if (ABL & 2) { P[0][t] += F.ua[t] + F.va0[t]; P[1][t] += F.va1[t]; }
+            else {
+            P[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.ua[t], F.va0[t], (FIRST && t == 0) ? zero4 : P[0], 0, 0, 0);
+            P[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.ua[t], F.va1[t], (FIRST && t == 0) ? zero4 : P[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 3) dma_piece(t, fr_);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            P[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[t], vb0[t], P[0], 0, 0, 0);
-            P[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[t], vb1[t], P[1], 0, 0, 0);
+            if (ABL & 2) { P[0][t] += F.ub[t] + F.vb0[t]; P[1][t] += F.vb1[t]; }
+            else {
+            P[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.ub[t], F.vb0[t], P[0], 0, 0, 0);
+            P[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.ub[t], F.vb1[t], P[1], 0, 0, 0);
+            }
         }
-        unsigned char* const t_ = st0; st0 = st1; st1 = st2; st2 = t_;
+#if W4F_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        dma_advance();
+        W4F_MARK(tl_burst);
     };
 
     for (int xi = 0; xi < 6; ++xi) {
 #pragma unroll
         for (int nu = 0; nu < 6; ++nu) {
-            for (int cc = 0; cc < p.cchunks; ++cc) chunk();
-            // end of position (xi, nu): R[j] += A^T[j][nu] * M, M cleared
+            chunk(TrueT{}, F0, F1);
+            chunk(FalseT{}, F1, F0);
+            for (int cc = 2; cc < p.cchunks; cc += 2) { chunk(FalseT{}, F0, F1); chunk(FalseT{}, F1, F0); }
+            // end of position (xi, nu): R[j] += A^T[j][nu] * M  (the next position's first MFMAs restart M from zero)
+            if (ABL & 32) continue;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -249,81 +329,95 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
                         for (int e = 0; e < 4; ++e) R[j][b][e] = fmaf(P[b][e], cf, R[j][b][e]);
                     }
                 }
-                P[b] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         // end of patch row xi: Y[i][j] += A^T[i][xi] * R[j], R cleared (coefficients by value: xi is a run-time index)
         const float c1 = xi == 0 || xi == 5 ? 0.f : xi == 1 ? 1.f : xi == 2 ? -1.f : xi == 3 ? 0.5f : -2.f;
         const float cfi[4] = {xi == 5 ? 0.f : 1.f, c1, c1 * c1, xi == 5 ? 1.f : c1 * c1 * c1};
 #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (cfi[i] == 0.f) continue;                  // (wave-uniform: rows 0 and 5 of the patch reach one output row each)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Y[i][j][b][e] = fmaf(R[j][b][e], cfi[i], Y[i][j][b][e]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) R[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    w4f_wait_vmcnt<0>();                                   // (the repeated requests of the last chunks: nothing may land in a retired workgroup's LDS)
+#if defined(YV3_MEASURE) && defined(W4F_TIMELINE)
+    const unsigned long long tl_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- epilogue: 16 outputs; output (i, j) of tile t goes to pixel (4 ty + i, 4 tx + j).
+    // accumulator element e of block b: channel n0 + 16 wid + 4 (lane >> 4) + e, tile m0 + 16 b + (lane & 15): a lane holds 16 bytes of
+    // consecutive channels per (output, block), a wave instruction writes 64-byte runs of 16 tiles; the four waves' runs of one tile make
+    // up its 256 contiguous bytes (merged in L2).  Straight from the registers: no transpose, no barrier; the residual rows of the next
+    // patch row are requested while this one is scaled and stored (through an LDS transpose with one barrier per output and the residual
+    // requested per output, the epilogue was 25 % of the launch: profiles/r06e_wino4_ablations.txt).
+    const int cw = n0 + 16 * wid + 4 * fq;                 // this lane's first channel
+    const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + cw);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cw);
+    long long pix[2];                                      // pixel index of (b, 4 ty, 4 tx) of my two tiles, -1: no such tile
+    int py[2], px[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int t = m0 + 16 * b + fr;
+        if (t < p.T) {
+            const int tt = p.th * p.tw;
+            const int bi = t / tt, rem = t - bi * tt;
+            const int ty = rem / p.tw, tx = rem - ty * p.tw;
+            py[b] = 4 * ty; px[b] = 4 * tx;
+            pix[b] = ((long long)bi * p.H + py[b]) * p.W + px[b];
+        } else { pix[b] = -1; py[b] = px[b] = 0; }
+    }
+    auto out_off = [&](int i, int j, int b) -> long long {
+        const bool ok = pix[b] >= 0 && py[b] + i < p.H && px[b] + j < p.W;
+        return ok ? (pix[b] + (long long)i * p.W + j) * p.Cout + cw : -1;
+    };
+    f32x4 rr[2][4][2];                                     // residual rows: [patch row parity][j][block]
+    auto load_res = [&](int i) {
+#pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
+                const long long off = out_off(i, j, b);
+                rr[i & 1][j][b] = off >= 0 ? *reinterpret_cast<const f32x4*>(p.res + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+    if (p.res) load_res(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < ((ABL & 1) ? 1 : 4); ++i) {
+        if (p.res && i + 1 < 4) load_res(i + 1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Y[i][j][b][e] = fmaf(R[j][b][e], cfi[i], Y[i][j][b][e]);
-                R[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long long off = out_off(i, j, b);
+                f32x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(Y[i][j][b][e], al[e], be[e]);
+                    if (p.act == YV3_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+                    q[e] = p.res ? v + rr[i & 1][j][b][e] : v;
+                }
+                if (off >= 0) *reinterpret_cast<f32x4*>(p.y + off) = q;
             }
     }
-    w4f_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                          // the ring is dead: its LDS becomes the epilogue's two transpose tiles
-
-    // ---- epilogue: 16 outputs; output (i, j) of tile t goes to pixel (4 ty + i, 4 tx + j).
-    // accumulator element e of block b: channel n0 + 16 wid + 4 (lane >> 4) + e, tile m0 + 16 b + (lane & 15)
-    float* const ep = reinterpret_cast<float*>(lds);
-    const int cw = 16 * wid + 4 * fq;                      // this lane's first channel inside the workgroup's 64
-    const f32x4 al = *reinterpret_cast<const f32x4*>(p.alpha + n0 + cw);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + n0 + cw);
-    // store side: thread -> (row = tid / 16 (+16), 4 channels (tid % 16) * 4)
-    const int sr = tid >> 4, sc = (tid & 15) << 2;
-    long long pix[2];                                      // pixel index of (b, 4 ty, 4 tx) of my two rows' tiles, -1: no such tile
-    int py[2], px[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int t = m0 + sr + 16 * h;
-        if (t < p.T) {
-            const int tt = p.th * p.tw;
-            const int b = t / tt, rem = t - b * tt;
-            const int ty = rem / p.tw, tx = rem - ty * p.tw;
-            py[h] = 4 * ty; px[h] = 4 * tx;
-            pix[h] = ((long long)b * p.H + py[h]) * p.W + px[h];
-        } else { pix[h] = -1; py[h] = px[h] = 0; }
+#if defined(YV3_MEASURE) && defined(W4F_TIMELINE)
+    if (blockIdx.x == W4F_TIMELINE && lane == 0) {
+        const unsigned long long tl_end = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0);
+        float* dbg = p.y + wid * 8;
+        dbg[0] = (float)tl_sync / nk; dbg[1] = (float)tl_burst / nk; dbg[2] = (float)tl_fold / nk; dbg[3] = (float)(tl_loop_end - tl_entry);
+        dbg[4] = (float)(tl_end - tl_loop_end); dbg[5] = (float)nk;
     }
-#pragma unroll
-    for (int o = 0; o < 16; ++o) {
-        const int i = o >> 2, j = o & 3;
-        float* const tile = ep + (o & 1) * (BMT * EP_LD);
-        long long off[2];
-        f32x4 rr[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool ok = pix[h] >= 0 && py[h] + i < p.H && px[h] + j < p.W;
-            off[h] = ok ? (pix[h] + (long long)i * p.W + j) * p.Cout + n0 + sc : -1;
-            rr[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.res && ok) rr[h] = *reinterpret_cast<const f32x4*>(p.res + off[h]);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x4 q;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = fmaf(Y[i][j][b][e], al[e], be[e]);
-                if (p.act == YV3_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
-                q[e] = v;
-            }
-            *reinterpret_cast<f32x4*>(tile + (16 * b + fr) * EP_LD + cw) = q;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (off[h] >= 0) {
-                f32x4 q = *reinterpret_cast<const f32x4*>(tile + (sr + 16 * h) * EP_LD + sc);
-                if (p.res) { q[0] += rr[h][0]; q[1] += rr[h][1]; q[2] += rr[h][2]; q[3] += rr[h][3]; }
-                *reinterpret_cast<f32x4*>(p.y + off[h]) = q;
-            }
-        }
-    }
+#endif
 }
 
 }  // namespace
@@ -331,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
 // U = G g G^T of a 3x3 filter bank, [cout][cin][6][6] fp32 (device) -> the GEMM stage's packed image (cout % 64 == 0, cin % 32 == 0)
 extern "C" int yv3_pack_wino4_weight_f32(const float* u_oc66, float* packed, int cout, int cin, void* stream) {
     if (!u_oc66 || !packed || cout <= 0 || cin <= 0) return YV3_EINVAL;
-    if (cout % 64 || cin % 32) return YV3_ESHAPE;
+    if (cout % 64 || cin % 64) return YV3_ESHAPE;
     const long long n4 = (long long)cout * cin * 9;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u_oc66, packed, cout, cin);
     YV3_CHECK_LAUNCH();
@@ -353,7 +447,7 @@ long long yv3_wino4_f32_workgroups(const yv3_conv_desc* d) {
 int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s) {
     const int th = (d->H + 3) / 4, tw = (d->W + 3) / 4;
     const long long T = (long long)d->B * th * tw;
-    if (T > 0x7fffffffLL || d->cout % BNC || d->cout_pad != d->cout || d->cin % 32 || d->k != 3 || d->stride != 1 || d->cin_up) return YV3_ESHAPE;
+    if (T > 0x7fffffffLL || d->cout % BNC || d->cout_pad != d->cout || d->cin % 64 || d->k != 3 || d->stride != 1 || d->cin_up) return YV3_ESHAPE;
     if (!d->w_wino4) return YV3_EINVAL;
     if (!d->wino_ws || d->wino_ws_bytes < yv3_wino4_workspace_bytes(d->B, d->H, d->W, d->cin)) return YV3_EWORKSPACE;
     float* v = (float*)d->wino_ws;
@@ -370,8 +464,7 @@ int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s) {
     p.pos_stride = T * d->cin;
     if (!p.alpha) return YV3_EINVAL;
     const dim3 grid((unsigned)(((T + BMT - 1) / BMT) * p.nblk_n));
-    const size_t pipe = (size_t)NSTAGE * STAGE, epi = (size_t)2 * BMT * EP_LD * sizeof(float);
-    hipLaunchKernelGGL(conv_wino4_f32_kernel, grid, dim3(256), pipe > epi ? pipe : epi, s, p);
+    hipLaunchKernelGGL(conv_wino4_f32_kernel, grid, dim3(256), (size_t)NSTAGE * STAGE + W4F_EXTRA_LDS, s, p);
     YV3_CHECK_LAUNCH();
     return 0;
 }

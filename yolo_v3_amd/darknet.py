@@ -276,6 +276,10 @@ class YoloNet(nn.Module):
     # ---- HIP execution
     def engine(self, dtype=None):
         dtype = self.math_mode if dtype is None else dtype
+        # a network whose activations once left the fp16 range of F32H2 runs in the fall-back mode from then on (engine.range_fallback;
+        # ``net.strict_range = True``: raise instead)
+        if dtype == _engine.F32H2 and self.__dict__.get("_range_fallback") is not None and not getattr(self, "strict_range", False):
+            dtype = self._range_fallback
         eng = self._engines.get(dtype)
         if eng is None:
             eng = self._engines[dtype] = _engine.Engine(self, dtype)
@@ -303,6 +307,7 @@ class YoloNet(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engines"] = {}
+        state.pop("_range_fallback", None)
         state.pop("_detectors", None)
         state.pop("_sharded_detectors", None)
         return state

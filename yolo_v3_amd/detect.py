@@ -139,11 +139,18 @@ class Detector:
             mark(name)
 
     def _choose_lanes(self):
-        """Automatic lane count: a pure function of the batch shape -- two lanes from TWO_LANES_MIN_PIXELS upwards -- provided a
-        stream pair that really runs concurrently exists on this GPU (`concurrent_stream_pair`: a yes/no probe, not a stopwatch).
-        No timing, no collective: every rank of a sharded run computes the same answer from the same shape, and `bench.py`
-        prints each rank's choice."""
+        """Automatic lane count: a function of the batch shape -- two lanes from TWO_LANES_MIN_PIXELS upwards -- provided a
+        stream pair that really runs concurrently exists on this GPU (`concurrent_stream_pair`: a yes/no probe, not a stopwatch, but
+        still an observation of this GPU at this moment: a rank whose GPU is busy with something else may answer "no", run one lane
+        and say so in a warning and in `bench.py`'s per-rank table).  No collective: the shape rule is the same on every rank, the
+        final choice is per rank."""
         streams = concurrent_stream_pair(self.device, self.engine.lane_choices)
+        if streams is None and not self.engine.lane_choices.get("one_lane_warned"):
+            import warnings
+            self.engine.lane_choices["one_lane_warned"] = True
+            warnings.warn("yolo_v3_amd: no pair of HIP streams ran concurrently on %s when this Detector was built (GPU shared with another "
+                          "process?): a batch of this size normally runs as two lanes (+4...9 %%), this one runs as one; the probe is repeated "
+                          "by the next Detector of this network (up to three times)" % (self.device,), RuntimeWarning)
         self._build_plans(2 if streams is not None else 1, streams)
 
     def _pick_stream_pair(self):
@@ -218,20 +225,38 @@ class Detector:
         fits = int(meta[B:2 * B].max()) <= hc
         return meta[:2 * B], (self._host_boxes if fits else boxes), int(meta[2 * B])
 
+    def recover(self, err):
+        """A kernel status word came back set.  StreamKTimeout: the engine drops the stream-K schedule; RangeOverflow in the default
+        mode: this detector moves to the fall-back engine (F32X3: same planes pipeline, fp32 range; `engine.range_fallback`).  True when
+        the batch can be run again (the next `run_device` rebuilds the plans), False when the error stands."""
+        from .engine import StreamKTimeout, RangeOverflow
+        if isinstance(err, StreamKTimeout):
+            self.engine.disable_stream_k()
+            return True
+        if isinstance(err, RangeOverflow):
+            fb = self.engine.range_fallback()
+            if fb is None:
+                return False
+            fb.ensure_packed()
+            self.engine = fb
+            self._generation = None                  # run_device rebuilds plans (and the graph) from the new engine
+            return True
+        return False
+
     def run_checked(self, imgs):
         """run_device + fetch + status check -> (host counts, boxes); a stream-K hand-over time-out (the GPU was shared with another
-        small-batch caller, engine.StreamKTimeout) switches the schedule off for this engine and the batch is run again."""
-        from .engine import StreamKTimeout
-        for attempt in (0, 1):
+        small-batch caller, engine.StreamKTimeout) switches the schedule off for this engine, a value beyond the fp16 range in the
+        default mode (engine.RangeOverflow) moves the detector to F32X3, and the batch is run again."""
+        from .engine import StreamKTimeout, RangeOverflow
+        for attempt in (0, 1, 2):
             boxes, counts = self.run_device(imgs)
             host_counts, bx, status = self.fetch(boxes, counts)
             try:
                 self.engine.raise_if_overflowed(self.plan, status)
                 return host_counts, bx
-            except StreamKTimeout:
-                if attempt:
+            except (StreamKTimeout, RangeOverflow) as e:
+                if attempt == 2 or not self.recover(e):
                     raise
-                self.engine.disable_stream_k()
 
     def __call__(self, imgs):
         host_counts, bx = self.run_checked(imgs)
@@ -279,8 +304,14 @@ def streams_run_concurrently(a, b, device):
 def concurrent_stream_pair(device, cache=None, tries=6):
     """Two HIP streams of `device` that run concurrently (None when none of `tries` fresh streams pairs with the first);
     remembered in `cache["stream_pair"]` (the engine's lane_choices: one probe per engine)."""
-    if cache is not None and "stream_pair" in cache:
+    if cache is not None and cache.get("stream_pair") is not None:
         return cache["stream_pair"]
+    # a NEGATIVE answer is not remembered for ever (ADVICE r5): the probe watches wall time, and a GPU that was busy with another
+    # process when the first detector was built can make a tiny kernel miss the spin.  Up to three constructions re-probe; after
+    # that the engine keeps its single lane (with one warning from `Detector._choose_lanes`)
+    if cache is not None:
+        if cache.get("stream_pair_misses", 0) >= 3:
+            return None
     pair = None
     if not hasattr(torch.cuda, "_sleep"):            # (a torch build without the spin kernel: two fresh streams, unprobed)
         pair = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
@@ -295,7 +326,10 @@ def concurrent_stream_pair(device, cache=None, tries=6):
                 pair = [first, other]
                 break
     if cache is not None:
-        cache["stream_pair"] = pair
+        if pair is None:
+            cache["stream_pair_misses"] = cache.get("stream_pair_misses", 0) + 1
+        else:
+            cache["stream_pair"] = pair
     return pair
 
 

@@ -225,5 +225,13 @@ def detect_sharded(net, imgs, num_classes=None, obj_conf_thr=0.5, nms_thr=0.4, u
            net.math_mode, bool(force_collective), group)        # (the group OBJECT: an id() can be reused after a group is collected)
     sd = cached_detector(net, key, lambda: ShardedDetector(net, b_pad, x.shape[2], x.shape[3], obj_conf_thr, nms_thr, use_nms,
                                                            cap, dtype, group, force_collective), sharded=True)
+    from .engine import StreamKTimeout, RangeOverflow
     with torch.no_grad():
-        return sd.assemble(sd.run_device(x), spans)                       # assemble: the single host sync
+        for attempt in (0, 1, 2):
+            try:
+                return sd.assemble(sd.run_device(x), spans)               # assemble: the single host sync
+            except (StreamKTimeout, RangeOverflow) as e:
+                # the status word is OR-ed over the ranks' payloads: EVERY rank sees the same error and takes the same branch, so the
+                # repeated call (one more collective) stays symmetric (the sharded path used to raise where detect() recovers)
+                if attempt == 2 or not sd.det.recover(e):
+                    raise

@@ -62,6 +62,10 @@ class StreamKTimeout(_ffi.Yv3Error):
     """The kernels' status bit 1: a stream-K hand-over did not arrive (see Engine.raise_if_overflowed)."""
 
 
+class RangeOverflow(_ffi.Yv3Error):
+    """The kernels' status bit 0: a value left the fp16 range of the F32H2 planes (or BF16's first layer) and was saturated."""
+
+
 class PackedConv:
     """Device-side parameters of one convolution in kernel layout."""
     __slots__ = ("spec", "w", "alpha", "beta", "cout_pad", "w_wino", "alpha_wino", "w_wino4")
@@ -196,7 +200,7 @@ def pack_conv(module, spec, dtype, winograd=False, winograd4=True):
                                         cout_pad, dtype, s), "yv3_pack_conv_weight")
     if winograd and wino_eligible(spec, dtype):
         ww, aw = pack_wino(w_orig, alpha_bn, spec, cout_pad, dtype)
-        w4 = pack_wino4(w_orig, spec) if (dtype == F32 and winograd4 and spec.cout % 64 == 0 and cout_pad == spec.cout) else None
+        w4 = pack_wino4(w_orig, spec) if (dtype == F32 and winograd4 and spec.cout % 64 == 0 and spec.cin % 64 == 0 and cout_pad == spec.cout) else None
         return PackedConv(spec, wp, alpha, beta, cout_pad, ww, aw, w4)
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
@@ -713,7 +717,8 @@ class Engine:
         return x
 
     OVERFLOW_MSG = ("an activation exceeded the fp16 range (|v| > 65504) and was saturated: math mode F32H2 cannot "
-                    "represent this network/input; set net.math_mode = yolo_v3_amd.F32X3 (or F32) and rerun")
+                    "represent this network/input; set net.math_mode = yolo_v3_amd.F32X3 (or F32) and rerun "
+                    "(net.strict_range = False, the default, does that by itself)")
     OVERFLOW_MSG_BF16 = ("the first layer of math mode BF16 runs on the fp16 matrix cores and needs |input| <= 4094 and "
                          "|weight| <= 255 (csrc/conv0.hip); this input / these weights exceed that and were saturated: "
                          "use net.math_mode = yolo_v3_amd.F32X3 (or F32)")
@@ -728,7 +733,22 @@ class Engine:
                 raise StreamKTimeout("a stream-K accumulator hand-over timed out: the schedule needs all of its workgroups resident at once "
                                      "and something else (another stream / thread / process running small batches) held part of the GPU.  "
                                      "Callers that share the GPU set net.stream_k = False (or net.deterministic = True)")
-            raise _ffi.Yv3Error(self.OVERFLOW_MSG_BF16 if self.dtype == BF16 else self.OVERFLOW_MSG)
+            raise RangeOverflow(self.OVERFLOW_MSG_BF16 if self.dtype == BF16 else self.OVERFLOW_MSG)
+
+    def range_fallback(self):
+        """After a RangeOverflow in the default mode: the engine that takes over -- F32X3, the same plane pipeline on three bf16
+        planes (fp32's exponent range, 24 significant bits) -- or None when there is none to fall back to (``net.strict_range = True``:
+        the caller wants the error; BF16: a reduced-precision mode the caller chose).  The choice is remembered on the network
+        (``YoloNet.engine`` hands out the fall-back engine wherever F32H2 is asked for from now on) and announced once."""
+        if self.dtype != F32H2 or getattr(self.net, "strict_range", False):
+            return None
+        import warnings
+        if getattr(self.net, "_range_fallback", None) is None:
+            warnings.warn("yolo_v3_amd: an activation left the fp16 range of math mode F32H2 (|v| > 65504); this network now runs in "
+                          "F32X3 (three bf16 planes: fp32 range, 24 bits, ~1.9x the time) -- set net.math_mode = F32X3 / F32 to avoid the "
+                          "first, discarded pass, or net.strict_range = True to get an error instead", RuntimeWarning)
+            self.net._range_fallback = F32X3
+        return self.net.engine(F32X3)
 
     def disable_stream_k(self):
         """After a StreamKTimeout: this engine stops using the stream-K schedule (plans are rebuilt without its workspace; holders
@@ -757,7 +777,14 @@ class Engine:
             B, _, H, W = x.shape
             plan = self.plan(B, H, W)
             if self.dtype in (F32H2, BF16) and plan.flags_event is not None and plan.flags_event.query():
-                self.raise_if_overflowed(plan, int(plan.flags_host[0]))
+                try:
+                    self.raise_if_overflowed(plan, int(plan.flags_host[0]))
+                except StreamKTimeout:                    # (net.async_forward: the EARLIER call's result is invalid -- say so -- but repair the future)
+                    self.disable_stream_k()
+                    raise
+                except RangeOverflow:
+                    self.range_fallback()
+                    raise
             if dets is None:
                 dets = torch.empty((B, plan.N, plan.attrib), device=x.device, dtype=torch.float32)
             self.run_convs(plan, x, dets)
@@ -775,4 +802,14 @@ class Engine:
                             raise
                         self.disable_stream_k()               # (fall back instead of failing the call)
                         return self.forward(x, dets, _retry=False)
+                    except RangeOverflow:                     # (the default mode computes where the reference computes)
+                        fb = self.range_fallback()
+                        if fb is None:
+                            raise
+                        return fb.forward(x, dets)
+                else:
+                    # asynchronous callers: a time-out / saturation seen at the start of the NEXT call cannot be repaired for the call that
+                    # produced it; the schedule / mode is switched for the calls that follow and the error still tells the caller that the
+                    # earlier result is invalid (raise_if_overflowed at the top of this function)
+                    pass
         return dets, plan
