@@ -208,7 +208,7 @@ typedef struct yv3_conv_desc {
     const float* alpha_wino;
     void*        wino_ws;
     size_t       wino_ws_bytes;
-    /* Winograd F(4x4,3x3) path of the YV3_F32 kernels (k = 3, stride 1, cin_up = 0, cout % 64 == 0, cin % 64 == 0; csrc/conv_wino4_f32.hip): when
+    /* Winograd F(4x4,3x3) path of the YV3_F32 kernels (k = 3, stride 1, cin_up = 0, cout % 64 == 0, cin == 64 or cin % 128 == 0; csrc/conv_wino4_f32.hip): when
        w_wino4 is not NULL the layer may run as  V = B^T d B over 6x6 input patches at stride 4 (points 0, 1, -1, 1/2, -2, inf; fp32;
        written to wino_ws as [36][T][cin], T = B*ceil(H/4)*ceil(W/4): yv3_wino4_workspace_bytes)  ->  thirty-six T x cout x cin GEMMs on
        v_mfma_f32_16x16x4_f32, folded on the fly into the sixteen outputs of every tile: 4x fewer matrix instructions than the direct
@@ -237,7 +237,7 @@ size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin);
 
 /* Size of yv3_conv_desc.wino_ws that the F(4x4,3x3) form of a YV3_F32 layer needs (never more than yv3_wino_workspace_bytes for
  * H, W >= 4).  U [cout][cin][6][6] fp32 = G g G^T (points 0, 1, -1, 1/2, -2, inf; computed by the caller, in fp64 and rounded once)
- * -> the GEMM stage's packed image of cout*cin*36 floats; cout % 64 == 0, cin % 64 == 0. */
+ * -> the GEMM stage's packed image of cout*cin*36 floats; cout % 64 == 0, cin == 64 or a multiple of 128. */
 size_t yv3_wino4_workspace_bytes(int B, int H, int W, int cin);
 int yv3_pack_wino4_weight_f32(const float* u_oc66, float* packed, int cout, int cin, void* stream);
 

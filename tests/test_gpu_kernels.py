@@ -903,12 +903,12 @@ def test_winograd_f32_conv_vs_fp64(cin, cout, B, H, W, res):
 @pytest.mark.parametrize("cin,cout,B,H,W,res", [(64, 128, 2, 20, 28, True), (128, 256, 2, 13, 13, True), (256, 512, 3, 26, 26, False),
                                                 (512, 1024, 2, 13, 13, True), (256, 128, 1, 7, 5, True), (128, 256, 3, 52, 52, True),
                                                 (64, 64, 1, 4, 4, False), (128, 192, 5, 19, 19, True), (256, 512, 40, 13, 13, True),
-                                                (128, 256, 1, 1, 9, True), (192, 128, 2, 6, 3, False)])
+                                                (128, 256, 1, 1, 9, True), (384, 128, 2, 6, 3, False)])
 def test_winograd4_f32_conv_vs_fp64(cin, cout, B, H, W, res):
     """fp32-MFMA mode (YV3_F32): the Winograd F(4x4,3x3) form (csrc/conv_wino4_f32.hip; points 0, 1, -1, 1/2, -2, inf) of
     conv_bn_relu(3x3, s1) (+ residual): pictures whose sides are and are not multiples of 4 (13, 19, 26, 7x5, 1x9: the last tile row / column
-    hangs over the edge by 1-3 pixels), tile counts that are not multiples of the workgroup's 32 (M tails), 64-wide channel blocks, 6 chunks per
-    position (cin 192), every output written exactly once (NaN-filled buffer).  Against fp64: 3e-5 * max(1,|ref|) (direct kernel: 2e-5; the form's
+    hangs over the edge by 1-3 pixels), tile counts that are not multiples of the workgroup's 32 (M tails), 64-wide channel blocks, 12 chunks per
+    position (cin 384), every output written exactly once (NaN-filled buffer).  Against fp64: 3e-5 * max(1,|ref|) (direct kernel: 2e-5; the form's
     transforms add ~1.5x, tools/winograd_f32_gate.py), against the direct fp32 kernel and the F(2x2) form: 3e-5.  The form query must say 2."""
     mode = _ffi.F32
     m = _rand_cbr(cin, cout, 3, 1, seed=cin + cout + H)

@@ -436,7 +436,7 @@ int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
     }
     // F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer matrix instructions than direct.  Its workgroups are 64 channels x 32 tiles of 4x4 pixels,
     // two per CU: taken when they fill at least half of those slots (tune[0] == 10: never, 11: whenever the filters are there)
-    if (d->w_wino4 && d->wino_ws && k3 && d->stride == 1 && !dual && d->cout % 64 == 0 && d->cin % 64 == 0 && d->cout_pad == d->cout && d->alpha && d->tune[0] != 10) {
+    if (d->w_wino4 && d->wino_ws && k3 && d->stride == 1 && !dual && d->cout % 64 == 0 && (d->cin == 64 || d->cin % 128 == 0) && d->cout_pad == d->cout && d->alpha && d->tune[0] != 10) {
         if ((d->options & YV3_OPT_WINO_ALWAYS) || d->tune[0] == 11 || yv3_wino4_f32_workgroups(d) >= yv3_num_cu())
             return d->wino_ws_bytes < yv3_wino4_workspace_bytes(d->B, d->H, d->W, d->cin) ? YV3_EWORKSPACE : YV3_FORM_WINOGRAD4;
     }

@@ -46,9 +46,7 @@ constexpr int ROWB = 128;                      // bytes per LDS row: one 32-chan
 constexpr int U_BYTES = BNC * ROWB;            // 8 KB
 constexpr int V_BYTES = BMT * ROWB;            // 4 KB
 constexpr int STAGE = U_BYTES + V_BYTES;       // 12 KB
-#ifndef W4F_NSTAGE
-#define W4F_NSTAGE 3
-#endif
+#define W4F_NSTAGE 4                             // (the main loop's stage indices are compile-time constants for FOUR stages)
 #ifndef W4F_PRIO
 #define W4F_PRIO 3                              // s_setprio(1) around a chunk's MFMAs: +2 % on the launches' time in the network (profiles/r06i_*)
 #endif
@@ -79,6 +77,7 @@ struct Wino4Params {
     int nblk_n;              // Cout / 64
     int act;
     long long pos_stride;    // T * C
+    unsigned u_bytes, v_bytes;   // sizes of the two DMA sources (buffer descriptors)
 };
 
 template <int N> __device__ __forceinline__ void w4f_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -162,6 +161,10 @@ __device__ __forceinline__ constexpr float at_coef(int j, int nu) {
          : (j == 3 ? 1.f : 0.f);
 }
 
+// CCH2: two chunks per transform position (cin 64); else a multiple of four (cin % 128 == 0) -- either way every chunk's ring stage
+// is known at compile time (four stages; a position starts at stage 0, or 0 / 2 alternately), so fragment reads and DMA targets
+// are immediate offsets and the DMA sources scalar bases: NO vector-ALU instruction in the steady-state loop but the MFMAs.
+template <bool CCH2>
 __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -173,28 +176,36 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
     const int m0 = (bid / p.nblk_n) * BMT;
     const int nk = 36 * p.cchunks;
 
-    // ---- DMA sources.  Weight side: the packed image is the LDS image; wave w copies 1 KB pieces 2w and 2w+1 of a chunk's 8 KB.
-    const float* usrc = p.u + ((long long)nb * nk) * (BNC * 32) + (2 * wid) * 256 + lane * 4;
+    // ---- DMA sources: buffer loads (buffer_load_dwordx4 ... offen lds): a scalar byte offset that advances by scalar adds + a per-lane
+    // byte offset that never changes -- no vector-ALU address arithmetic in the loop.
+    // Weight side: the packed image is the LDS image; wave w copies 1 KB pieces 2w and 2w+1 of a chunk's 8 KB.
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, (int)p.v_bytes, 0x00020000);
+    unsigned usoff = (unsigned)((((long long)nb * nk) * (BNC * 32) + (2 * wid) * 256) * 4);
+    const unsigned uoff = lane * 16;
     // V side: wave w stages tile rows [8w, 8w+8): lane -> row lane/8, physical slot lane%8, source slot = physical ^ swz(row)
     const int vrow = 8 * wid + (lane >> 3);
     const int vt = min(m0 + vrow, p.T - 1);                              // (rows past the last tile re-read it; never stored)
-    const float* vsrc = p.v + (long long)vt * p.C + (((lane & 7) ^ w4f_swz(vrow)) << 2);
+    unsigned vsoff = (unsigned)m0 * (unsigned)p.C * 4u;
+    const unsigned voff = (unsigned)(vt - m0) * (unsigned)p.C * 4u + ((((unsigned)lane & 7u) ^ (unsigned)w4f_swz(vrow)) << 4);
     int pf_c = 0;                                                         // channel offset of the chunk being requested
     int pf_k = 0;                                                         // its chunk number
     // one chunk = three 1 KB pieces per wave; `dma_piece(i, stage)` requests piece i, `dma_advance()` moves on to the next chunk --
     // past the last chunk the requests repeat it (a constant number of requests per iteration keeps the vmcnt waits exact)
     auto dma_piece = [&](int i, unsigned char* stage) {
         if (ABL & 8) return;
-        if (i == 0)      __builtin_amdgcn_global_load_lds(W4F_GPTR(usrc), W4F_LPTR(stage + (2 * wid) * 1024), 16, 0, 0);
-        else if (i == 1) __builtin_amdgcn_global_load_lds(W4F_GPTR(usrc + 256), W4F_LPTR(stage + (2 * wid + 1) * 1024), 16, 0, 0);
-        else             __builtin_amdgcn_global_load_lds(W4F_GPTR(vsrc + pf_c), W4F_LPTR(stage + U_BYTES + wid * 1024), 16, 0, 0);
+        if (i == 0)      __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, W4F_LPTR(stage + (2 * wid) * 1024), 16, uoff, usoff, 0, 0);
+        // (the instruction's immediate offset moves BOTH the memory address and the LDS address: piece 1 = piece 0's bases + 1024)
+        else if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, W4F_LPTR(stage + (2 * wid) * 1024), 16, uoff, usoff, 1024, 0);
+        else             __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, W4F_LPTR(stage + U_BYTES + wid * 1024), 16, voff, vsoff, 0, 0);
     };
     auto dma_advance = [&]() {
         if (pf_k + 1 < nk) {
             ++pf_k;
-            usrc += BNC * 32;
+            usoff += BNC * 32 * 4;
+            vsoff += 128;
             pf_c += 32;
-            if (pf_c == p.C) { pf_c = 0; vsrc += p.pos_stride; }
+            if (pf_c == p.C) { pf_c = 0; vsoff += (unsigned)(p.pos_stride - p.C) * 4u; }
         }
     };
 
@@ -251,9 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2);
 #endif
     Frag F0 = read_frag(lds), F1;
-    int s_cur = 0;                                         // stage of the chunk whose fragments are in registers
     using TrueT = std::integral_constant<bool, true>;
-    using FalseT = std::integral_constant<bool, false>;   // (host: cin % 64 == 0 -> an even number of chunks per position)
+    using FalseT = std::integral_constant<bool, false>;
 
     // one chunk (its fragments already in registers): [wait for my pieces of the NEXT chunk] [barrier: the next chunk is complete, and
     // everybody has taken this chunk's fragments out of its stage] [request chunk + NSTAGE into that stage, read the next chunk's
@@ -269,8 +279,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
 #endif
     // FIRST: the first chunk of a transform position -- its first MFMAs start from a zero accumulator (an inline constant: the product
     // blocks are never cleared by vector instructions, which cost a wave ~30 cycles each while its SIMD's other wave issues MFMAs)
-    auto chunk = [&](auto first_c, const Frag& F, Frag& G) {
+    // S: the ring stage of THIS chunk (compile time)
+    auto chunk = [&](auto first_c, auto stage_c, const Frag& F, Frag& G) {
         constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int S = decltype(stage_c)::value;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         W4F_MARK(tl_fold);
         w4f_wait_vmcnt<3 * (NSTAGE - 2)>();
@@ -278,9 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         W4F_MARK(tl_sync);
-        unsigned char* const fr_ = lds + s_cur * STAGE;
-        s_cur = s_cur + 1 == NSTAGE ? 0 : s_cur + 1;
-        G = read_frag(lds + s_cur * STAGE);
+        unsigned char* const fr_ = lds + S * STAGE;
+        G = read_frag(lds + ((S + 1) % NSTAGE) * STAGE);
 #if W4F_PRIO == 3
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -310,14 +321,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
         W4F_MARK(tl_burst);
     };
 
-    for (int xi = 0; xi < 6; ++xi) {
-#pragma unroll
-        for (int nu = 0; nu < 6; ++nu) {
-            chunk(TrueT{}, F0, F1);
-            chunk(FalseT{}, F1, F0);
-            for (int cc = 2; cc < p.cchunks; cc += 2) { chunk(FalseT{}, F0, F1); chunk(FalseT{}, F1, F0); }
+    auto position = [&](auto nu_c) {
+        constexpr int nu = decltype(nu_c)::value;
+        {
+            using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+            using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+            if constexpr (CCH2) {                          // 12 chunks per patch row: positions start at stage 0, 2, 0, 2, 0, 2
+                if constexpr ((nu & 1) == 0) { chunk(TrueT{}, S0{}, F0, F1); chunk(FalseT{}, S1{}, F1, F0); }
+                else                         { chunk(TrueT{}, S2{}, F0, F1); chunk(FalseT{}, S3{}, F1, F0); }
+            } else {
+                chunk(TrueT{}, S0{}, F0, F1); chunk(FalseT{}, S1{}, F1, F0); chunk(FalseT{}, S2{}, F0, F1); chunk(FalseT{}, S3{}, F1, F0);
+                for (int cc = 4; cc < p.cchunks; cc += 4) {
+                    chunk(FalseT{}, S0{}, F0, F1); chunk(FalseT{}, S1{}, F1, F0); chunk(FalseT{}, S2{}, F0, F1); chunk(FalseT{}, S3{}, F1, F0);
+                }
+            }
             // end of position (xi, nu): R[j] += A^T[j][nu] * M  (the next position's first MFMAs restart M from zero)
-            if (ABL & 32) continue;
+            if (ABL & 32) return;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -331,6 +350,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
                 }
             }
         }
+    };
+    for (int xi = 0; xi < 6; ++xi) {
+        position(std::integral_constant<int, 0>{}); position(std::integral_constant<int, 1>{}); position(std::integral_constant<int, 2>{});
+        position(std::integral_constant<int, 3>{}); position(std::integral_constant<int, 4>{}); position(std::integral_constant<int, 5>{});
         // end of patch row xi: Y[i][j] += A^T[i][xi] * R[j], R cleared (coefficients by value: xi is a run-time index)
         const float c1 = xi == 0 || xi == 5 ? 0.f : xi == 1 ? 1.f : xi == 2 ? -1.f : xi == 3 ? 0.5f : -2.f;
         const float cfi[4] = {xi == 5 ? 0.f : 1.f, c1, c1 * c1, xi == 5 ? 1.f : c1 * c1 * c1};
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_f32_kernel(const Wino4Param
 // U = G g G^T of a 3x3 filter bank, [cout][cin][6][6] fp32 (device) -> the GEMM stage's packed image (cout % 64 == 0, cin % 32 == 0)
 extern "C" int yv3_pack_wino4_weight_f32(const float* u_oc66, float* packed, int cout, int cin, void* stream) {
     if (!u_oc66 || !packed || cout <= 0 || cin <= 0) return YV3_EINVAL;
-    if (cout % 64 || cin % 64) return YV3_ESHAPE;
+    if (cout % 64 || (cin != 64 && cin % 128)) return YV3_ESHAPE;
     const long long n4 = (long long)cout * cin * 9;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u_oc66, packed, cout, cin);
     YV3_CHECK_LAUNCH();
@@ -447,7 +470,7 @@ long long yv3_wino4_f32_workgroups(const yv3_conv_desc* d) {
 int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s) {
     const int th = (d->H + 3) / 4, tw = (d->W + 3) / 4;
     const long long T = (long long)d->B * th * tw;
-    if (T > 0x7fffffffLL || d->cout % BNC || d->cout_pad != d->cout || d->cin % 64 || d->k != 3 || d->stride != 1 || d->cin_up) return YV3_ESHAPE;
+    if (T > 0x7fffffffLL || d->cout % BNC || d->cout_pad != d->cout || (d->cin != 64 && d->cin % 128) || d->k != 3 || d->stride != 1 || d->cin_up) return YV3_ESHAPE;
     if (!d->w_wino4) return YV3_EINVAL;
     if (!d->wino_ws || d->wino_ws_bytes < yv3_wino4_workspace_bytes(d->B, d->H, d->W, d->cin)) return YV3_EWORKSPACE;
     float* v = (float*)d->wino_ws;
@@ -463,8 +486,12 @@ int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s) {
     p.cchunks = d->cin / 32; p.nblk_n = d->cout / BNC; p.act = d->act;
     p.pos_stride = T * d->cin;
     if (!p.alpha) return YV3_EINVAL;
+    const unsigned long long vb = 36ull * T * d->cin * 4, ub = 36ull * d->cout * d->cin * 4;
+    if (vb > 0xffffffffull || ub > 0xffffffffull) return YV3_ESHAPE;        // (32-bit buffer offsets: V of at most 4 GB)
+    p.u_bytes = (unsigned)ub; p.v_bytes = (unsigned)vb;
     const dim3 grid((unsigned)(((T + BMT - 1) / BMT) * p.nblk_n));
-    hipLaunchKernelGGL(conv_wino4_f32_kernel, grid, dim3(256), (size_t)NSTAGE * STAGE + W4F_EXTRA_LDS, s, p);
+    if (p.cchunks == 2) hipLaunchKernelGGL(conv_wino4_f32_kernel<true>, grid, dim3(256), (size_t)NSTAGE * STAGE + W4F_EXTRA_LDS, s, p);
+    else                hipLaunchKernelGGL(conv_wino4_f32_kernel<false>, grid, dim3(256), (size_t)NSTAGE * STAGE + W4F_EXTRA_LDS, s, p);
     YV3_CHECK_LAUNCH();
     return 0;
 }

@@ -200,7 +200,7 @@ def pack_conv(module, spec, dtype, winograd=False, winograd4=True):
                                         cout_pad, dtype, s), "yv3_pack_conv_weight")
     if winograd and wino_eligible(spec, dtype):
         ww, aw = pack_wino(w_orig, alpha_bn, spec, cout_pad, dtype)
-        w4 = pack_wino4(w_orig, spec) if (dtype == F32 and winograd4 and spec.cout % 64 == 0 and spec.cin % 64 == 0 and cout_pad == spec.cout) else None
+        w4 = pack_wino4(w_orig, spec) if (dtype == F32 and winograd4 and spec.cout % 64 == 0 and (spec.cin == 64 or spec.cin % 128 == 0) and cout_pad == spec.cout) else None
         return PackedConv(spec, wp, alpha, beta, cout_pad, ww, aw, w4)
     return PackedConv(spec, wp, alpha, beta, cout_pad)
 
