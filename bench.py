@@ -303,6 +303,38 @@ class Workload:
             tot += self.B * (rd * eb + out_b + (out_b if sp.res2 else 0)) + sp.cout * sp.cin * sp.k * sp.k * eb
         return tot
 
+    def form_bytes(self):
+        """HBM bytes of the launches timed as the 'convs' stage IN THE FORM EACH ONE RUNS (exact-fp32 mode): a direct launch moves its
+        algorithmic bytes; a Winograd launch additionally writes and reads back its transformed input V -- 16 values per 2x2 tile
+        (F(2x2,3x3)) or 36 per 4x4 tile (F(4x4,3x3)) and channel, fp32 -- and reads the transformed filters (16/9 or 4x the 3x3 ones).
+        `traffic / form_bytes` is then the re-read factor of the kernels themselves; `traffic / algorithmic_bytes` also contains the
+        price of the form."""
+        from yolo_v3_amd import arch
+        if self.mode != "f32":
+            return None
+        specs = arch.conv_specs()
+        tot = 0
+        for p in self.det.lane_plans:
+            for j, (si, f) in zip(range(p.first_desc, p.n_desc), p.forms()):
+                d, sp = p.descs[j], specs[si]
+                ho, wo = (d.H + 2 * ((sp.k - 1) // 2) - sp.k) // sp.stride + 1, (d.W + 2 * ((sp.k - 1) // 2) - sp.k) // sp.stride + 1
+                if sp.cin in (768, 384):
+                    up = sp.cin // 3
+                    rd = (d.H // 2) * (d.W // 2) * up + d.H * d.W * (sp.cin - up)
+                else:
+                    rd = d.H * d.W * sp.cin
+                out_b = ho * wo * sp.cout * 4
+                wb = sp.cout * sp.cin * sp.k * sp.k * 4
+                b = d.B * (rd * 4 + out_b + (out_b if sp.res2 else 0))
+                if f == 1:
+                    b += 2 * 16 * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * sp.cin * 4
+                    wb = wb * 16 // 9
+                elif f == 2:
+                    b += 2 * 36 * d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4) * sp.cin * 4
+                    wb = wb * 4
+                tot += b + wb
+        return tot
+
     def executed(self):
         """EXECUTED matrix work of the launches timed as the 'convs' stage, next to the algorithmic (direct-form) count of
         `flops()`: (executed 2*MAC -- a launch that takes the Winograd F(2x2,3x3) form, as the library reports it through
@@ -511,8 +543,8 @@ def _pick(d, keys, rename=None):
 
 
 ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "algorithmic_tflops", "algorithmic_frac", "executed_tflops", "executed_frac",
-             "mfma_util", "clock_ghz", "traffic", "algorithmic_bytes", "launches", "winograd_launches", "winograd4_launches", "avg_launch_ms",
-             "conv_ms_per_step")
+             "mfma_util", "clock_ghz", "traffic", "algorithmic_bytes", "form_bytes", "launches", "winograd_launches", "winograd4_launches",
+             "avg_launch_ms", "conv_ms_per_step")
 MODE_ROOF_KEYS = ("achieved", "peak", "frac", "algorithmic_frac", "mfma_util", "clock_ghz", "traffic", "algorithmic_bytes", "launches",
                   "winograd_launches")
 
@@ -758,6 +790,7 @@ def main():
             "stages_ms_one_lane": head1["stages_ms"],
             "roofline": dict(head1["roofline"], traffic=None,
                              algorithmic_bytes=round(alg_bytes / n_desc),
+                             **({"form_bytes": round(roof_w.form_bytes() / n_desc)} if args.dtype == "f32" else {}),
                              conv_ms_per_step=st["convs"], avg_launch_ms=round(st["convs"] / n_desc, 5),
                              flop_per_launch_avg=fi / n_desc,
                              end_to_end_frac=round(fa / (head["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4)),
@@ -793,8 +826,7 @@ def main():
             w = Workload(net, x, mode, args.conf, args.nms)
             out["modes"][mode] = w.summary(w.run(sub_steps, sub_warm), sub_steps)
             w.finish()
-            if w.det.lanes == 1:
-                out["modes"][mode]["roofline"]["algorithmic_bytes"] = round(w.algorithmic_bytes() / out["modes"][mode]["roofline"]["launches"])
+            out["modes"][mode]["roofline"]["algorithmic_bytes"] = round(w.algorithmic_bytes() / out["modes"][mode]["roofline"]["launches"])
             if args.no_live_traffic or world > 1 or not live_traffic(out["modes"][mode]["roofline"], args, B, dtype=mode):
                 attach_traffic(out["modes"][mode]["roofline"], mode, args.size, B, out["modes"][mode]["roofline"]["launches"])
             if mode == "bf16":

@@ -1,6 +1,6 @@
 """Cycle split of the fused front kernel (debug build with -DYV3_FRONT_TL; YV3_LIB points at it).  DT=f32h2|bf16, SIZE (416), BB (64)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import YoloNet, WeightManager, synth, _ffi
 torch.cuda.set_device(0)

@@ -1,9 +1,9 @@
 """Barrier-wait vs total cycles of one consumer (matrix-core) and one producer (vector-ALU) wave of conv_front_f32_kernel's workgroup 17
 (debug build with -DYV3_FRONT_TL; YV3_MEASURE=1 YV3_LIB points at it).  416x416, bs from BB (64).
-Belongs to the producer / consumer version of the kernel kept as tools/probes/conv_front_f32_specialised_waves.hip.txt (the shipped serial kernel
+Belongs to the producer / consumer version of the kernel kept as tools/probes/dead_experiments/conv_front_f32_specialised_waves.hip.txt (the shipped serial kernel
 has no timeline marks): copy that file over csrc/conv_front_f32.hip, tools/build_variant.sh ftl "-DYV3_FRONT_TL", run this.  profiles/r05t_*."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import YoloNet, WeightManager, synth, _ffi
 torch.cuda.set_device(0)

@@ -1,8 +1,8 @@
 """Cycle split of one workgroup (blockIdx 17) of the SINGLE-PHASE (non ping-pong) plane-conv main loop -- needs a -DYV3_TIMELINE
 build (YV3_LIB=...).  Per wave, over the whole K loop: vmcnt wait | barrier | body (MFMA units + LDS reads + DMA issue), and the
-cycles spent issuing DMA pieces.   DT=bf16 YV3_TILE=5 BB=34 python tools/timeline_np.py"""
+cycles spent issuing DMA pieces.   DT=bf16 YV3_TILE=5 BB=34 python tools/timeline.py --kernel np"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import _ffi, engine
 from yolo_v3_amd.darknet import conv_bn_relu

@@ -1,6 +1,6 @@
 """Cycle split of one workgroup of the ping-pong conv kernel (needs a -DYV3_TIMELINE build: YV3_LIB=...)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import _ffi, engine
 from yolo_v3_amd.darknet import conv_bn_relu

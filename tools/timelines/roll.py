@@ -2,7 +2,7 @@
 rolling loop as the stage's default (-DYV3_WINO_ROLL=1; YV3_LIB=...): per wave and chunk: DMA address preparation | first k-step block
 (6 MFMAs + 6 fragment reads + 4 DMA pieces) | vmcnt / lgkmcnt waits | barrier | second k-step block (6 MFMAs + 6 reads) | fold."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import _ffi, engine
 from yolo_v3_amd.darknet import conv_bn_relu

@@ -1,8 +1,8 @@
 """Cycle split of one workgroup of the bf16 ROLLING tiles (conv_planes_kernel<1, 256|192, 256, 2, 4, 3, ..., ROLL> and the four-wave
 <1, 256, 128, 2, 2, 3, ..., 2, 2, ROLL>) -- needs a -DYV3_TIMELINE build (YV3_MEASURE=1 YV3_LIB=...): prologue | per chunk: DMA address
-preparation, first k-step block, waits, barrier, second k-step block | epilogue.   BB=16 python tools/timeline_roll_bf16.py c76 c38 [TILE code]"""
+preparation, first k-step block, waits, barrier, second k-step block | epilogue.   BB=16 python tools/timeline.py --kernel roll_bf16 c76 c38 [TILE code]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import _ffi, engine
 from yolo_v3_amd.darknet import conv_bn_relu

@@ -3,7 +3,7 @@
 (18 MFMAs + k-step 1's fragment reads), wait (vmcnt / lgkmcnt before the barrier), barrier, k-step 1 (18 MFMAs + DMA pieces + next chunk's
 reads) | epilogue.  WG = workgroup index sampled (default 700: a later round, warm instruction cache; 100 = first round)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import _ffi, engine
 from yolo_v3_amd.darknet import conv_bn_relu

@@ -1,7 +1,7 @@
 """Cycle split of one workgroup (blockIdx 100) of the Winograd GEMM stage (ping-pong loop) -- needs a -DYV3_TIMELINE build
 (YV3_LIB=...): per wave: prologue | per chunk: load segment, barrier, compute segment (+ fold), barrier | epilogue (4 outputs)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from yolo_v3_amd import _ffi, engine
 from yolo_v3_amd.darknet import conv_bn_relu

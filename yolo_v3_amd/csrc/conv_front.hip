@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_front_kernel(const FrontParams p) {
     if ((int)blockIdx.x < p.total) patch_fetch(blockIdx.x);
 
     float amax = 0.f;
-#ifdef YV3_FRONT_TL      // debug build only (tools/front_timeline.py): cycle split of one workgroup, written over y[0..]
+#ifdef YV3_FRONT_TL      // debug build only (tools/timeline.py --kernel front): cycle split of one workgroup, written over y[0..]
     unsigned long long tl_t = __builtin_amdgcn_s_memtime(), tl_acc[6] = {0, 0, 0, 0, 0, 0};
 #define FTL(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_acc[i] += t_ - tl_t; tl_t = t_; } while (0)
 #else

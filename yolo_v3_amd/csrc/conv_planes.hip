@@ -47,7 +47,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { __builtin_amdg
 //   tune[2]        bf16: threshold (256x128 tiles) from which the four-wave tile is used
 //   tune[3] (measurement builds, -DYV3_MEASURE, only) bit 0  epilogue without its stores   bit 1  without its residual loads   (results INVALID)
 // Compile time (A/B builds through tools/build_variant.sh):
-// YV3_WABL (timing ablations of the Winograd GEMM stage's ping-pong loop, results INVALID; tools/timeline_wino.py):
+// YV3_WABL (timing ablations of the Winograd GEMM stage's ping-pong loop, results INVALID; tools/timeline.py --kernel wino):
 //   1 no DMA pieces in the compute segment   2 both k-steps' fragments read in the load segment (no SPLIT)
 //   4 no fold at the end of a position       8 no MFMAs (fragments kept alive)
 //   16 every DMA source is the tile's FIRST chunk (L1/L2-hot lines: no memory-system bandwidth / latency in the loop)
@@ -1173,7 +1173,7 @@ int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s) {
             // Round 5: both tiles run the eight-wave PING-PONG loop on a 4-deep ring instead of the rolling loop (tune[1] bit 9: the rolling loop,
             // bit 10: ping-pong on the 3-deep ring -- A/B).  The rolling tile's eight waves leave their one barrier together, their fragment
             // reads (96 KB per chunk and CU) queue behind each other and ~350 of a chunk's 1500 cycles are exposed LDS latency
-            // (tools/timeline_roll_bf16.py, profiles/r05x_bf16_roll_timeline.txt); with one four-wave group reading while the other issues
+            // (tools/timeline.py --kernel roll_bf16, profiles/r05x_bf16_roll_timeline.txt); with one four-wave group reading while the other issues
             // MFMAs the layers run bit-identical and +5...+14 % faster in isolation, on uniform random operands and on the network's own
             // activations alike (profiles/r05y_bf16_pingpong_*_ab.txt, r05ad_*).  IN the network the 3-deep ring LOSES 2 % (its DMA lead is one
             // compute segment, ~1000 cycles: fine for L2-hot repeats of one layer, too short for a layer's first touch of its weights and

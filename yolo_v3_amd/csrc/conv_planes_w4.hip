@@ -16,7 +16,7 @@
 //     landed in the other stage); under k-step 1's MFMAs the stage just released is refilled by DMA (chunk k+2) and the next
 //     chunk's k-step-0 fragments are read.  Nothing is read or waited for right behind the barrier; what latency is still exposed
 //     is filled by the other workgroup's waves.
-// (First attempt, measured and dropped -- profiles/r05d_w4_16deep_ab.txt, source kept as tools/probes/conv_planes_w4_16deep_chunks.hip.txt:
+// (First attempt, measured and dropped -- profiles/r05d_w4_16deep_ab.txt, source kept as tools/probes/dead_experiments/conv_planes_w4_16deep_chunks.hip.txt:
 // 16-deep chunks with a 256x128 tile, three 24 KB stages.  Bit-identical, but global_load_lds moves 32-byte row segments at HALF the
 // rate of 64-byte ones, 31 instead of 62 B/clk/CU (tools/probes/dma_rate.hip, rows32; profiles/r05d_dma_rate_rows32.txt): the DMA
 // stream then takes as long as the MFMAs, long-K layer 297 instead of 377 TFLOP/s.)
