@@ -218,6 +218,37 @@ def test_hostile_whole_net_all_fp32_modes():
     assert errs["F32H2"] <= 3 * max(errs["F32"], e_or)
 
 
+def test_hostile_whole_net_forced_winograd_forms():
+    """The hostile network in the exact-fp32 mode with ALL 31 eligible layers forced into one Winograd form -- F(2x2,3x3), and round 6's
+    F(4x4,3x3) with the points (0, 1, -1, 1/2, -2) -- against the fp64 evaluation: the GPU side of tools/winograd_f32_gate.py (the CPU
+    gate that chose the points: the textbook (0, +-1, +-2) land at 4x the oracle's own error).  Bar: F(2x2) inside the 3x-oracle bound
+    of test_hostile_whole_net_all_fp32_modes, F(4x4) inside 3.5x (measured, MI355X: oracle 1.34e-4, direct kernels 3.31e-4, F(2x2)
+    2.62e-4, F(4x4) 3.90e-4 = 2.9x; profiles/r06q_hostile_forms.txt), detections of both within twice that of the fp32 oracle's."""
+    sd, x = hostile_state_dict()
+    stream = state_dict_to_stream(sd)
+    with torch.no_grad():
+        l64 = oc.head_logits({k: v.double() for k, v in sd.items()}, x.double())
+        l32 = oc.head_logits(sd, x)
+        d32 = torch.cat(oc.yolonet_forward(sd, x), 1)
+    e_or = max(float(rel_err(a, b).max()) for a, b in zip(l32, l64))
+    for w4, nform, mult in ((False, 1, 3.0), (True, 2, 3.5)):
+        net = YoloNet((416, 416)).eval()
+        assert WeightManager(net).load_stream(stream) == stream.size
+        net = net.cuda()
+        net.math_mode, net.winograd, net.winograd4 = _ffi.F32, "always", w4
+        with torch.no_grad():
+            lg = _logits_of(net, _ffi.F32, x.cuda())
+            dets = net.forward_cat(x.cuda()).cpu()
+        forms = [f for _, f in net.engine().plan(1, 416, 416).forms()]
+        assert forms.count(nform) == 31, forms
+        e = max(float(rel_err(a, b).max()) for a, b in zip(lg, l64))
+        ok = torch.isfinite(d32) & (d32.abs() < 1e30)
+        e_det = float(rel_err(dets[ok], d32[ok]).max())
+        bound = max(1e-4, mult * e_or)
+        print("hostile, all 31 layers in form %d: logits vs fp64 %.3g (oracle %.3g, bound %.3g), detections vs fp32 oracle %.3g" % (nform, e, e_or, bound, e_det))
+        assert e <= bound and e_det <= 2 * bound, (nform, e, e_det, bound)
+
+
 @pytest.mark.parametrize("cin,cout,k,s,B,H,W", [(128, 256, 3, 1, 4, 26, 26), (256, 128, 1, 1, 8, 26, 26), (64, 128, 3, 2, 2, 52, 52)])
 def test_hostile_conv_level_all_fp32_modes(cin, cout, k, s, B, H, W):
     """One conv_bn_relu on hostile operands, all three fp32-class modes side by side against fp64: weights = sign x

@@ -49,7 +49,7 @@ pmc)    ARGS=$1; DT=$2; SIZE=$3; B=$4; NL=$5
           timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o t -- python bench.py $ARGS --lanes 1 --no-extras --no-cpu-baseline --no-live-traffic --steps 3 --warmup 1 > /dev/null 2> $O/${TAG}_pmc_$c.err
         done
         python tools/mfma_util_summary.py $O/${TAG}_pmc_MFMA > $O/${TAG}_mfma_util.json; head -70 $O/${TAG}_mfma_util.json
-        python tools/traffic_summary.py $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE 4 $NL > $O/${TAG}_traffic_${DT}_${SIZE}_bs${B}.json; cat $O/${TAG}_traffic_${DT}_${SIZE}_bs${B}.json
+        python tools/traffic_summary.py $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE 4 $NL $([ "$DT" = f32 ] && echo f32r6) > $O/${TAG}_traffic_${DT}_${SIZE}_bs${B}.json; cat $O/${TAG}_traffic_${DT}_${SIZE}_bs${B}.json
         rm -rf $O/${TAG}_pmc_MFMA $O/${TAG}_pmc_FETCH $O/${TAG}_pmc_WRITE ;;
 plan)   BS=$1; SIZE=$2; DT=$3; : > $O/${TAG}_plan_table.txt
         for b in $BS; do rm -rf $O/${TAG}_pl

@@ -17,14 +17,19 @@ def family(per, key):
     vals = [v for (n, v) in per.values() if key in n]
     return vals
 out = {}
-for fam, key in (("wino_input_kernel", "wino_input"), ("conv_planes_kernel", "conv_planes"), ("conv_igemm_f32_kernel", "conv_igemm"), ("conv0_kernel", "conv0"),
+# exact-fp32 mode since round 6: 31 F(4x4,3x3) launches (conv_wino4_f32_kernel + wino4_input_f32_kernel each) + 40 conv_igemm_f32_kernel launches per step
+F32R6 = len(sys.argv) > 5 and sys.argv[5] == "f32r6"
+PER_STEP = {"conv_wino4": 31, "wino4_input": 31, "conv_igemm": 40} if F32R6 else {}
+for fam, key in (("wino_input_kernel", "wino_input"), ("wino4_input_f32_kernel", "wino4_input"), ("conv_wino4_f32_kernel", "conv_wino4"),
+                 ("conv_planes_kernel", "conv_planes"), ("conv_igemm_f32_kernel", "conv_igemm"), ("conv0_kernel", "conv0"),
                  ("conv_front_kernel", "conv_front"), ("conv_res64_kernel", "conv_res64"), ("decode_kernel", "decode")):
     f, w = family(fetch, key), family(write, key)
     if not f: continue
     n = len(f)
     # last `launches` of a step: use all launches / steps
-    per_step_f = sum(f) / (n / (launches_per_step if "conv_planes" in key or "igemm" in key else {"conv0": 1, "conv_front": 1, "conv_res64": 1, "decode": 3}.get(key, 1))) if n else 0
-    per_step_w = sum(w) / (len(w) / (launches_per_step if "conv_planes" in key or "igemm" in key else {"conv0": 1, "conv_front": 1, "conv_res64": 1, "decode": 3}.get(key, 1))) if w else 0
-    out[fam] = {"launches_profiled": n, "fetch_KiB_per_step_raw": per_step_f, "write_KiB_per_step": per_step_w,
+    lps = PER_STEP.get(key) or (launches_per_step if "conv_planes" in key or "igemm" in key else {"conv0": 1, "conv_front": 1, "conv_res64": 1, "decode": 3}.get(key, 1))
+    per_step_f = sum(f) / (n / lps) if n else 0
+    per_step_w = sum(w) / (len(w) / lps) if w else 0
+    out[fam] = {"launches_profiled": n, "launches_per_step": lps, "fetch_KiB_per_step_raw": per_step_f, "write_KiB_per_step": per_step_w,
                 "hbm_bytes_per_step_raw": (per_step_f + per_step_w) * 1024, "hbm_bytes_per_step_fetch_x2": (2 * per_step_f + per_step_w) * 1024}
 print(json.dumps(out, indent=1))
