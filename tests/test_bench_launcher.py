@@ -54,6 +54,27 @@ def test_final_line_is_compact_for_a_full_result_object():
     assert not any("note" in k or k.endswith("_is") for k in c["roofline"])
 
 
+def test_final_line_of_the_round6_object_names_a_reference_precision_mode():
+    """VERDICT r5 #1 on a FULL result object of a round-6 run (profiles/r06z_bench_full.json): the compact line's top-level dtype is the
+    exact-fp32 mode, `roofline.frac` is the EXECUTED fraction (<= 1) with the algorithmic one beside it, the kernel family / traffic /
+    byte counts are there, and the product's default mode, f32x3 and bf16 are sub-objects with the same fields; still < 4 KB."""
+    import bench
+    full = json.load(open(os.path.join(REPO, "profiles", "r06z_bench_full.json")))
+    line = json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json"), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    c = json.loads(line)
+    assert c["dtype"].startswith("f32 (exact fp32") and c["config"]["workload"].startswith("416x416 bs=64")
+    r = c["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic_frac"] > r["frac"] and r["winograd4_launches"] == 31 and "conv_wino4_f32_kernel" in r["kernel"]
+    assert r["traffic"] > r["form_bytes"] > r["algorithmic_bytes"] > 0 and 0.0 < r["mfma_util"] <= 1.0
+    for k in ("f32h2", "f32x3", "bf16"):
+        assert {"value", "ms_per_step", "achieved", "peak", "frac", "algorithmic_frac", "launches"} <= set(c[k]), (k, c[k])
+        assert c[k]["frac"] <= 1.0
+    assert c["configs"]["1"]["value"] > 0 and "1_f32h2" in c["configs"]
+    assert c["cpu_baseline"]["kind"] == "port" and c["boxes_delta"]["matched"] == c["boxes_delta"]["ref"]
+
+
 def test_too_few_gpus_is_an_error_not_a_one_rank_run():
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     r = _run(["--gpus", str(have + 2), "--no-extras", "--steps", "1"])
