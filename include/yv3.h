@@ -216,7 +216,12 @@ typedef struct yv3_conv_desc {
        differ from the direct kernel by fp32 round-off (whole network: within 1.4x of the direct form's distance from an fp64
        evaluation on hostile data, equal on the headline data -- tools/winograd_f32_gate.py).  The library takes this form when its
        64-channel x 32-tile workgroups fill the chip (yv3_conv2d_form == YV3_FORM_WINOGRAD4), else F(2x2) by w_wino's rule, else the
-       direct kernel. */
+       direct kernel.  Schedule: one (32 tiles x 64 channels) item per workgroup while the items fill whole rounds of the chip (two
+       workgroups per CU); the items of a last, partial round are dealt out by patch row over all the slots -- an item split between
+       workgroups of one XCD is summed part by part in workgroup order through the hand-over area at the END of wino_ws (the last
+       yv3_wino4_workspace_bytes - V bytes: ZERO-FILLED once by the caller, then left alone; one wino_ws per stream).  Which items are
+       split depends on B: the same image is then summed in a different (fixed per shape) order at different batch sizes / positions;
+       YV3_OPT_WINO4_TILES keeps one item per workgroup.  A hand-over that times out sets bit 1 of *flags. */
     const void*  w_wino4;
 } yv3_conv_desc;
 
@@ -226,6 +231,8 @@ typedef struct yv3_conv_desc {
 #define YV3_OPT_WINO_ALWAYS 8u    /* Winograd stage whenever w_wino is set, whatever the tile count                                     */
 #define YV3_OPT_TWO_LANES   16u   /* the caller runs an equal launch sequence on a second stream at the same time (two lanes of one batch):
                                      the Winograd rule's lower bound counts both lanes' tiles (0.27 instead of 0.55 rounds per launch)  */
+#define YV3_OPT_WINO4_TILES 32u   /* F(4x4,3x3) stage: one item per workgroup only -- no even schedule (whose ranges wait for their partner
+                                     workgroups: callers that share the GPU with other work; results then do not depend on the batch size) */
 #define YV3_OPT_TILE_SHIFT  8     /* bits 8..15: force a tile configuration of the fp16-plane kernels (0 = automatic):
                                      1 = 256x128 / 8 waves, 2 = 128x128 / 8 waves, 3 = 128x128 / 4 waves, two workgroups per CU */
 
@@ -235,8 +242,8 @@ size_t yv3_conv_workspace_bytes(void);
 /* Size of yv3_conv_desc.wino_ws for a B x H x W x cin input (YV3_F32_F16X2). */
 size_t yv3_wino_workspace_bytes(int B, int H, int W, int cin);
 
-/* Size of yv3_conv_desc.wino_ws that the F(4x4,3x3) form of a YV3_F32 layer needs (never more than yv3_wino_workspace_bytes for
- * H, W >= 4).  U [cout][cin][6][6] fp32 = G g G^T (points 0, 1, -1, 1/2, -2, inf; computed by the caller, in fp64 and rounded once)
+/* Size of yv3_conv_desc.wino_ws that the F(4x4,3x3) form of a YV3_F32 layer needs: V + the hand-over area (never more than
+ * yv3_wino_workspace_bytes for H, W >= 4).  U [cout][cin][6][6] fp32 = G g G^T (points 0, 1, -1, 1/2, -2, inf; computed by the caller, in fp64 and rounded once)
  * -> the GEMM stage's packed image of cout*cin*36 floats; cout % 64 == 0, cin == 64 or a multiple of 128. */
 size_t yv3_wino4_workspace_bytes(int B, int H, int W, int cin);
 int yv3_pack_wino4_weight_f32(const float* u_oc66, float* packed, int cout, int cin, void* stream);

@@ -947,6 +947,57 @@ def test_winograd4_f32_conv_vs_fp64(cin, cout, B, H, W, res):
     assert _ffi.lib().yv3_conv2d_form(d) != 2
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(512, 1024, 1, 13, 13), (256, 512, 4, 26, 26), (128, 256, 2, 52, 52), (64, 128, 13, 104, 104),
+                                            (256, 128, 3, 19, 19)])
+def test_winograd4_f32_even_schedule(cin, cout, B, H, W):
+    """The F(4x4,3x3) stage's even schedule (round 6; include/yv3.h, yv3_conv_desc.w_wino4): tail items cut into 2 / 3 / 6 ranges of patch rows,
+    one workgroup each, summed through the hand-over area -- against one item per workgroup (tune[1] = 1).  Six parts (one row each) add the same
+    products in the same order: bit-identical; two / three parts re-associate the row sums: within 2e-6 * max|y|.  The status word stays 0, every
+    hand-over flag is back to zero, a second launch gives the same bits, YV3_OPT_WINO4_TILES means one item per workgroup, and -- 64 -> 128 at
+    104 x 104, 13 images: 550 items -- a tail behind a full round of the chip (512 whole-item workgroups + 38 items cut)."""
+    mode = _ffi.F32
+    lib = _ffi.lib()
+    m = _rand_cbr(cin, cout, 3, 1, seed=cin + cout + H).cuda()
+    sp = m._spec()
+    pc = engine.pack_conv(m, sp, mode)
+    pc.w_wino4 = engine.pack_wino4(m.conv.weight.detach().float().contiguous(), sp)
+    g = torch.Generator().manual_seed(H * 31 + W + B)
+    xg = (torch.rand(B, H, W, cin, generator=g) * 2 - 0.5).cuda()
+    rg = (torch.rand(B, H, W, cout, generator=g) - 0.5).cuda()
+    ws = torch.zeros(lib.yv3_wino4_workspace_bytes(B, H, W, cin), dtype=torch.uint8, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def run(tune1, tune2, options=0):
+        y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        d = engine.make_desc(pc, xg, y, B, H, W, rg, dtype=mode, flags=status)
+        d.w_wino4 = pc.w_wino4.data_ptr(); d.wino_ws = ws.data_ptr(); d.wino_ws_bytes = ws.numel()
+        d.options |= _ffi.OPT_WINO_ALWAYS | options
+        d.tune[1], d.tune[2] = tune1, tune2
+        assert lib.yv3_conv2d_form(d) == 2
+        _ffi.check(lib.yv3_conv2d(d, _ffi.stream_ptr()))
+        y1 = y.clone()
+        _ffi.check(lib.yv3_conv2d(d, _ffi.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all(), "an output element was not written"
+        assert torch.equal(y, y1), "two launches of one descriptor differ"
+        return y
+    tiles = run(1, 0)
+    scale = float(tiles.abs().max())
+    for parts in (6, 3, 2):
+        y = run(0, parts)
+        if parts == 6:
+            assert torch.equal(y, tiles), "six one-row parts must add the same products in the same order"
+        else:
+            assert float((y - tiles).abs().max()) <= 2e-6 * scale, "parts = %d: %g" % (parts, float((y - tiles).abs().max()))
+    run(0, 0)                                                # the library's own choice
+    assert torch.equal(run(0, 6, _ffi.OPT_WINO4_TILES), tiles)
+    assert int(status.item()) == 0
+    # the hand-over area is the last 512 * (256 KB + 4) + 256 bytes of the buffer (rounded down to 256); its flags sit in the last 128 KB part
+    area_off = (ws.numel() - (512 * (512 * 128 * 4 + 4) + 256)) & ~255
+    flags = ws[area_off + 1023 * 128 * 1024: area_off + 1023 * 128 * 1024 + 4 * 1023].view(torch.int32)
+    assert int((flags != 0).sum()) == 0, "a hand-over flag was left set"
+
+
 def test_eval_letterbox_and_scale_vs_oracle():
     """The evaluation pipeline's input preparation on the GPU (SURVEY 8f-1 eval variant; evaluate.py:211,213): ``IaaLetterbox(dim)``
     (box at ((out - box) // 2): one pixel off the utils rule for odd boxes) and ``iaa.Scale(dim)`` (plain bicubic resize), bit for bit

@@ -21,7 +21,7 @@ if os.environ.get("YV3_MEASURE") != "1":
 F32, BF16, F32X3, F32H2 = 0, 1, 2, 3
 ACT_LINEAR, ACT_LEAKY = 0, 1
 PP_EVAL, PP_PROB = 1, 2
-OPT_NO_PINGPONG, OPT_K3S1, OPT_WINO_EVEN, OPT_WINO_ALWAYS, OPT_TWO_LANES = 1, 2, 4, 8, 16
+OPT_NO_PINGPONG, OPT_K3S1, OPT_WINO_EVEN, OPT_WINO_ALWAYS, OPT_TWO_LANES, OPT_WINO4_TILES = 1, 2, 4, 8, 16, 32
 
 c_void_p, c_int, c_float, c_size_t, c_longlong = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_size_t, ctypes.c_longlong)

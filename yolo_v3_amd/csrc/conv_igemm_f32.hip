@@ -425,6 +425,7 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
 
 int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s);
 long long yv3_wino4_f32_workgroups(const yv3_conv_desc* d);
+bool yv3_wino4_f32_pays(const yv3_conv_desc* d);
 
 // Which form does this fp32 descriptor take: direct (0), Winograd F(2x2,3x3) (1) or F(4x4,3x3) (2)?  (exported through yv3_conv2d_form)
 int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
@@ -435,12 +436,12 @@ int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
         if ((long long)d->B * Ho * Wo > 0x7fffffffLL) return YV3_ESHAPE;
     }
     // F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer matrix instructions than direct.  Its workgroups are 64 channels x 32 tiles of 4x4 pixels,
-    // two per CU: taken from 0.3 workgroups per CU (tune[0] == 10: never, 11: whenever the filters are there).  Measured per layer, same box,
+    // two per CU: taken by yv3_wino4_f32_pays (tune[0] == 10: never, 11: whenever the filters are there).  Round 6, one item per workgroup, same box,
     // direct / F(2x2) / F(4x4) (profiles/r06o_wino4_forms_by_batch.txt): it is the fastest form of every eligible layer from 8 images of
     // 416x416 up (bs=8: 128->256 @52 0.139 / 0.117 / 0.070 ms, 256->512 @26 0.136 / 0.185 / 0.105; 64 workgroups: 0.187 / 0.337 / 0.182);
     // at 88 workgroups (bs=4 @52) 0.072 / 0.110 / 0.065, at 56 (bs=4 @26) 0.096 / 0.184 / 0.103 -- the crossover
     if (d->w_wino4 && d->wino_ws && k3 && d->stride == 1 && !dual && d->cout % 64 == 0 && (d->cin == 64 || d->cin % 128 == 0) && d->cout_pad == d->cout && d->alpha && d->tune[0] != 10) {
-        if ((d->options & YV3_OPT_WINO_ALWAYS) || d->tune[0] == 11 || yv3_wino4_f32_workgroups(d) * 10 >= 3 * (long long)yv3_num_cu())
+        if ((d->options & YV3_OPT_WINO_ALWAYS) || d->tune[0] == 11 || yv3_wino4_f32_pays(d))
             return d->wino_ws_bytes < yv3_wino4_workspace_bytes(d->B, d->H, d->W, d->cin) ? YV3_EWORKSPACE : YV3_FORM_WINOGRAD4;
     }
     if (!(d->w_wino && d->alpha_wino && k3 && d->stride == 1 && !dual && d->cout % 128 == 0 && d->cout_pad == d->cout)) return 0;

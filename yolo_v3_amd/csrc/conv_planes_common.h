@@ -35,10 +35,7 @@ struct ConvParamsP {
 // stream-K workspace geometry (yv3_conv_workspace_bytes): one 512-thread workgroup's accumulators per CU + one flag
 #define YV3_SK_MAX_WG 512
 #define YV3_SK_PART_BYTES (512 * 64 * 4)
-// ... and of the Winograd stage's even schedule (tail of yv3_conv_desc.wino_ws): four output accumulator sets per part
-#define YV3_WINO_SK_MAX_WG 512
-#define YV3_WINO_SK_PART_BYTES (512 * 128 * 4)
-static inline size_t yv3_wino_sk_bytes() { return (size_t)YV3_WINO_SK_MAX_WG * (YV3_WINO_SK_PART_BYTES + sizeof(int)) + 256; }
+// (the Winograd stages' hand-over area -- YV3_WINO_SK_* -- is in yv3_common.h: conv_wino4_f32.hip shares it)
 
 // IO ablations of the epilogue (bit 0 no stores, bit 1 no residual loads, bit 2 no decode arithmetic: results INVALID) exist only in
 // measurement builds (-DYV3_MEASURE: `make measure` / tools/build_variant.sh -> libyv3_measure.so / libyv3_<name>.so); the shipped

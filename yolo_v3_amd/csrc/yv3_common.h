@@ -27,6 +27,13 @@ static inline int yv3_num_cu() {
     return n >= 8 ? n & ~7 : 256;
 }
 
+// Hand-over area of the Winograd stages' even schedules (tail of yv3_conv_desc.wino_ws): YV3_WINO_SK_MAX_WG parts, then as many flags.
+// A part holds one workgroup's partial outputs: four output accumulator sets of a 512-thread workgroup (F(2x2), fp16 planes: 256 KB) or
+// the sixteen outputs of a 256-thread workgroup (F(4x4), exact fp32: 128 KB of it).
+#define YV3_WINO_SK_MAX_WG 512
+#define YV3_WINO_SK_PART_BYTES (512 * 128 * 4)
+static inline size_t yv3_wino_sk_bytes() { return (size_t)YV3_WINO_SK_MAX_WG * (YV3_WINO_SK_PART_BYTES + sizeof(int)) + 256; }
+
 // float -> bf16 bits, round to nearest even (NaN kept quiet)
 __host__ __device__ static inline u16 yv3_f2bf(float f) {
     union { float f; uint32_t u; } v; v.f = f;

@@ -246,7 +246,7 @@ def batch_split(B, ho, wo, cout_pad, ncu):
 
 
 def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, out_dtype=None, flags=None, workspace=None,
-              batch=None, wino_ws=None, two_lanes=False, wino_always=False):
+              batch=None, wino_ws=None, two_lanes=False, wino_always=False, wino4_tiles=False):
     """`batch` = (b0, nb): the descriptor covers images b0 .. b0+nb-1 of the [NP][B,...] plane tensors (plane dtypes only).
     `wino_always`: YV3_OPT_WINO_ALWAYS (``net.winograd = "always"``: the Winograd form on every eligible layer, whatever the
     tile count)."""
@@ -257,6 +257,8 @@ def make_desc(pc, x, y, B, H, W, residual=None, x2=None, cin_up=0, dtype=F32, ou
         d.options |= _ffi.OPT_TWO_LANES
     if wino_always:
         d.options |= _ffi.OPT_WINO_ALWAYS
+    if wino4_tiles:
+        d.options |= _ffi.OPT_WINO4_TILES
     for i, v in enumerate((measure_env("YV3_TUNE", "") or "0").split(",")[:4]):
         d.tune[i] = int(v or 0)
     d.x, d.x2, d.w = _ptr(x), _ptr(x2), _ptr(pc.w)
@@ -377,7 +379,8 @@ class Plan:
                 split = batch_split(B, ho, wo, pc.cout_pad, ncu)
             for part in ([None] if split is None else [(0, split[0]), (split[0], split[1])]):
                 descs.append(make_desc(pc, x, y, B, h, w, residual, x2, cin_up, dt, out_dtype, self.flags, self.workspace, batch=part,
-                                       wino_ws=self.wino_ws, two_lanes=two_lanes, wino_always=engine.wino_always))
+                                       wino_ws=self.wino_ws, two_lanes=two_lanes, wino_always=engine.wino_always,
+                                       wino4_tiles=engine.stream_k is False))
                 self.desc_spec.append(i)
             if y is not None:
                 self.layer_out[pc.spec.name] = y
@@ -750,6 +753,11 @@ class Engine:
             self.net._range_fallback = F32X3
         return self.net.engine(F32X3)
 
+    def checks_status(self):
+        """Does a forward of this engine have a kernel status word to look at?  F32H2 / BF16: fp16 saturation (+ stream-K hand-over);
+        F32: only the F(4x4) stage's even schedule can set it (hand-over time-out on a shared GPU) -- not with ``net.stream_k = False``."""
+        return self.dtype in (F32H2, BF16) or (self.dtype == F32 and self.winograd and self.winograd4 and self.stream_k is not False)
+
     def disable_stream_k(self):
         """After a StreamKTimeout: this engine stops using the stream-K schedule (plans are rebuilt without its workspace; holders
         of a Plan -- `Detector` -- see the new `generation`).  The results of the call that timed out are invalid and must be
@@ -776,7 +784,7 @@ class Engine:
             self.ensure_packed()
             B, _, H, W = x.shape
             plan = self.plan(B, H, W)
-            if self.dtype in (F32H2, BF16) and plan.flags_event is not None and plan.flags_event.query():
+            if self.checks_status() and plan.flags_event is not None and plan.flags_event.query():
                 try:
                     self.raise_if_overflowed(plan, int(plan.flags_host[0]))
                 except StreamKTimeout:                    # (net.async_forward: the EARLIER call's result is invalid -- say so -- but repair the future)
@@ -789,7 +797,7 @@ class Engine:
                 dets = torch.empty((B, plan.N, plan.attrib), device=x.device, dtype=torch.float32)
             self.run_convs(plan, x, dets)
             self.run_decode(plan, dets)
-            if self.dtype in (F32H2, BF16):
+            if self.checks_status():
                 plan.flags_host.copy_(plan.flags, non_blocking=True)
                 plan.flags_event = torch.cuda.Event()
                 plan.flags_event.record()
