@@ -424,6 +424,8 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
 }
 
 int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s);
+int yv3_conv2d_gemm1x1_f32(const yv3_conv_desc* d, hipStream_t s, long long* rows_done);      // csrc/conv_gemm_f32.hip: plain 1x1 layers, persistent DMA-fed GEMM
+bool yv3_gemm1x1_f32_takes(const yv3_conv_desc* d);
 long long yv3_wino4_f32_workgroups(const yv3_conv_desc* d);
 bool yv3_wino4_f32_pays(const yv3_conv_desc* d);
 
@@ -474,6 +476,19 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     if (form < 0) return form;
     if (form == YV3_FORM_WINOGRAD4) return yv3_conv2d_wino4_f32(d, s);
     if (form == YV3_FORM_WINOGRAD) return launch_wino_f32(d, p, s);
+    if (yv3_gemm1x1_f32_takes(d)) {
+        // plain 1x1 layer: whole rounds of the chip on the persistent GEMM, the rest (< half a round of its tiles) on the small tiles below
+        // (same K order per output element: same bits whoever computes a row)
+        long long done = 0;
+        const int rc = yv3_conv2d_gemm1x1_f32(d, s, &done);
+        if (rc || done >= M) return rc;
+        p.x += done * d->cin; p.y += done * d->cout;
+        p.M = (int)(M - done);
+        p.H = 1; p.W = p.M; p.Ho = 1; p.Wo = p.M;                              // (a 1x1 layer's rows are independent: the rest as one image of M' x 1 pixels)
+        const int np1 = d->cout_pad;
+        if (np1 % 128 == 0 || np1 % 64 == 0) { p.ntiles = np1 / 64; return np1 % 128 == 0 ? launch<64, 64, 2, 2>(p, false, false, s, pin) : launch<128, 64, 2, 2>(p, false, false, s, pin); }
+        return YV3_ESHAPE;
+    }
 
     // Tile selection: widest N tile the layer fills; for launches that would leave most of the
     // 256 CUs idle (small batch at 13x13 / 26x26) fall back to 64x64 tiles for 4x the blocks.
