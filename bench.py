@@ -72,11 +72,11 @@ DTYPE_NAME = {"f32": "f32 (exact fp32 MFMA)", "bf16": "bf16 (fp32 accumulate)",
               "f32h2": "f32h2: fp32 EMULATED by a 2-way fp16 split (22 significant bits, fp16 range; 3 fp16 MFMAs per product, fp32 accumulate)"}
 MFMAS_PER_PRODUCT = {"f32": 1, "bf16": 1, "f32x3": 6, "f32h2": 3}
 INSTR_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0, "f32h2": 2500.0}   # dense peak of the MFMA the mode issues
-KERNEL_NAME = {"f32": "conv_wino4_f32_kernel + conv_igemm_f32_kernel", "bf16": "conv_planes_kernel<1>", "f32x3": "conv_planes_kernel<3>",
+KERNEL_NAME = {"f32": "conv_wino4_f32_kernel + conv_igemm_f32_kernel + conv_gemm1x1_f32_kernel", "bf16": "conv_planes_kernel<1>", "f32x3": "conv_planes_kernel<3>",
                "f32h2": "conv_planes_kernel<2> + conv_planes_w4_kernel"}
 # kernels that make up the dominant family per mode (substring match on the rocprofv3 kernel names of the PMC child passes): the plane modes run the
 # eight-wave / Winograd kernels of conv_planes.hip AND, since round 5, the four-wave two-workgroups-per-CU kernel of conv_planes_w4.hip
-FAMILY = {"f32": ("conv_igemm_f32_kernel", "conv_wino4_f32_kernel"), "bf16": ("conv_planes_kernel", "conv_planes_w4_kernel"),
+FAMILY = {"f32": ("conv_igemm_f32_kernel", "conv_wino4_f32_kernel", "conv_gemm1x1_f32_kernel"), "bf16": ("conv_planes_kernel", "conv_planes_w4_kernel"),
           "f32x3": ("conv_planes_kernel", "conv_planes_w4_kernel"), "f32h2": ("conv_planes_kernel", "conv_planes_w4_kernel")}
 STAGES = ("conv0", "convs", "decode", "filter", "nms")
 
@@ -281,6 +281,12 @@ class Workload:
                                                                          for p in self.det.lane_plans)
         return 2.0 * sum(macs) * self.B, 2.0 * sum(macs[first:]) * self.B, plan.n_desc - plan.first_desc
 
+    def family_dispatches(self):
+        """Kernel dispatches of the mode's dominant family per 'convs' stage of one lane: one per descriptor, two for an exact-fp32 1x1 layer that
+        runs as persistent GEMM + small tiles (a Winograd launch's input transform is not in the family)."""
+        p = self.det.plan
+        return sum(1 if f != 0 else n for (_, f), n in zip(p.forms(), p.launches()))
+
     def algorithmic_bytes(self):
         """ALGORITHMIC HBM bytes of the launches timed as the 'convs' stage (one lane): every conv reads its input once, its
         residual once (second conv of a res_layer), its packed weights once and writes its output once.  Element size: 4 B in
@@ -451,7 +457,7 @@ def family_wall_ns(trace_csv, family):
 LIVE_TRAFFIC = {"ok": True}          # one failed pass (missing tool, time-out, crash) switches the live measurement off for the rest of the run
 
 
-def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=None, conf=None, nms=None):
+def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=None, conf=None, nms=None, dispatches_per_launch=1.0):
     """HBM bytes per launch of the dominant kernel family, measured for THIS binary on THIS box: two rocprofv3 --pmc passes
     (FETCH_SIZE, WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over a 3-step one-lane run of the same
     workload in child processes (counters cannot be sampled from inside this process).  traffic = (2*FETCH + WRITE) * 1024 /
@@ -527,7 +533,7 @@ def live_traffic(roof, args, B, timeout_s=60, dtype=None, size=None, weights=Non
         roof["mfma_util_note"] = ("PMC, third child pass of the same one-lane workload: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) "
                                   "over the launches of %s; clock = GRBM_GUI_ACTIVE/8 / their wall time (2.4 GHz nominal: the matrix pipe's "
                                   "share of the nominal peak is mfma_util * clock_ghz / 2.4)" % " + ".join(fam))
-    roof["traffic"] = round((2 * f + w) * 1024 / nf)
+    roof["traffic"] = round((2 * f + w) * 1024 / nf * dispatches_per_launch)     # per LAUNCH of the roofline object (= per descriptor)
     roof["traffic_source"] = "measured in this run"
     roof["traffic_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / %d profiled launches of %s: rocprofv3 --pmc "
                             "passes (one counter each; a third pass for the matrix pipe) over 3 one-lane steps of this workload in child processes, %.0f s; FETCH_SIZE "
@@ -731,7 +737,7 @@ def main():
         dist.all_gather_object(ranks, rank_info)                      # (after the timed region; every rank takes part)
     if rank == 0 and os.environ.get("YV3_DUMP_PLAN"):               # for tools/trace_layers.py: conv spec index of every launch
         p_ = main_w.det.plan
-        json.dump({"first_desc": p_.first_desc, "desc_spec": p_.desc_spec}, open(os.environ["YV3_DUMP_PLAN"], "w"))
+        json.dump({"first_desc": p_.first_desc, "desc_spec": p_.desc_spec, "desc_launches": p_.launches()}, open(os.environ["YV3_DUMP_PLAN"], "w"))
     head = main_w.summary(elapsed, args.steps)
 
     sub_steps, sub_warm = 10, 3
@@ -800,7 +806,7 @@ def main():
                                                 "mean what they say; the timed step above runs %d concurrent lanes" % (head1["value"], head1["ms_per_step"], lanes_used))
             out["roofline"]["two_lanes_section"] = {k: head["roofline"][k] for k in ("kernel", "achieved", "frac", "algorithmic_tflops", "algorithmic_frac", "launches",
                                                                                   "winograd_launches", "winograd4_launches")}
-        if args.no_live_traffic or world > 1 or not live_traffic(out["roofline"], args, B):
+        if args.no_live_traffic or world > 1 or not live_traffic(out["roofline"], args, B, dispatches_per_launch=roof_w.family_dispatches() / n_desc):
             attach_traffic(out["roofline"], args.dtype, args.size, B, n_desc)
         if args.dtype in ("f32x3", "f32h2"):
             nm = {"f32x3": 6, "f32h2": 3}[args.dtype]

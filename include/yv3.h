@@ -261,6 +261,11 @@ int yv3_conv2d(const yv3_conv_desc* desc, void* stream);
 #define YV3_FORM_WINOGRAD4 2     /* YV3_F32: F(4x4,3x3), 36 multiplications per 4x4 outputs and channel pair (4x fewer than direct) */
 int yv3_conv2d_form(const yv3_conv_desc* desc);
 
+/* How many kernels does yv3_conv2d launch for this descriptor on the current device?  1; 2 for the Winograd forms (input transform + GEMM
+ * stage) and for a YV3_F32 1x1 layer whose whole rounds of tiles run on the persistent GEMM (csrc/conv_gemm_f32.hip) and the rest on the
+ * small tiles.  Negative: the YV3_E* code yv3_conv2d would return.  Launches nothing; profiling tools use it to map a kernel trace to layers. */
+int yv3_conv2d_launches(const yv3_conv_desc* desc);
+
 /* Run `n` convolutions back to back on `stream` (one host call for a whole network plan). */
 int yv3_conv2d_sequence(const yv3_conv_desc* descs, int n, void* stream);
 

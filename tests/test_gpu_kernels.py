@@ -998,51 +998,60 @@ def test_winograd4_f32_even_schedule(cin, cout, B, H, W):
     assert int((flags != 0).sum()) == 0, "a hand-over flag was left set"
 
 
-@pytest.mark.parametrize("cin,cout,B,H,W,bn", [(256, 128, 3, 52, 52, True), (512, 256, 5, 26, 26, True), (1024, 512, 2, 13, 13, True), (128, 64, 2, 104, 104, True),
-                                               (96, 192, 1, 37, 23, True), (256, 128, 20, 52, 52, True), (64, 64, 1, 5, 3, False), (128, 256, 64, 26, 26, True)])
-def test_gemm1x1_f32_equals_tiles_bitwise(cin, cout, B, H, W, bn):
-    """Exact-fp32 mode, plain 1x1 layers: the persistent DMA-fed GEMM (csrc/conv_gemm_f32.hip, round 6) against conv_igemm_f32's tiles
-    (tune[0] = 13) -- same K order per output element, so the same bits: with every row on the GEMM (tune[0] = 14, tune[1] = 3), with the library's
-    split (whole rounds of the chip on the GEMM, the rest on the small tiles) and by its own rule; pixel counts that are not multiples of the
-    128 / 256-row tiles (37 x 23, 5 x 3: rows past the last pixel are requested clamped and never stored -- NaN-filled buffer + canary behind it),
-    three chunks per tile (cin 96), the 256 x 64 tile (cout 64 / 192), a plain conv (no BN: bias, linear), more than one tile per workgroup
-    (20 x 52 x 52: 423 tiles on 256 CUs; 64 x 26 x 26: 676).  Against fp64 as the direct kernel (2e-5)."""
+@pytest.mark.parametrize("cin,cout,B,H,W,k,stride,bn", [(256, 128, 3, 52, 52, 1, 1, True), (512, 256, 5, 26, 26, 1, 1, True), (1024, 512, 2, 13, 13, 1, 1, True),
+                                                        (128, 64, 2, 104, 104, 1, 1, True), (96, 192, 1, 37, 23, 1, 1, True), (256, 128, 20, 52, 52, 1, 1, True),
+                                                        (64, 64, 1, 5, 3, 1, 1, False), (128, 256, 64, 26, 26, 1, 1, True),
+                                                        (64, 128, 3, 52, 52, 3, 2, True), (128, 256, 2, 27, 19, 3, 2, True), (96, 128, 1, 13, 13, 3, 1, True),
+                                                        (128, 128, 40, 26, 26, 3, 2, True)])
+def test_gemm_f32_equals_tiles_bitwise(cin, cout, B, H, W, k, stride, bn):
+    """Exact-fp32 mode: the persistent DMA-fed GEMM (csrc/conv_gemm_f32.hip, round 6) against conv_igemm_f32's tiles (tune[0] = 13) -- same K
+    order per output element, so the same bits: with every row on the GEMM (tune[0] = 14, tune[1] = 3), with the library's split (whole
+    rounds of the chip on the GEMM, the rest on the tiles) and by its own rule.  Plain 1x1 layers: pixel counts that are not multiples of the
+    128 / 256-row tiles (37 x 23, 5 x 3: rows past the last pixel are requested clamped and never stored -- NaN-filled buffer + canary behind
+    it), three chunks per tile (cin 96), the 256 x 64 tile (cout 64 / 192), a plain conv (no BN: bias, linear), more than one tile per
+    workgroup (20 x 52 x 52: 423 tiles on 256 CUs; 64 x 26 x 26: 676).  3x3 layers (the kernel's K3 operand path, taken with tune[0] = 14 only):
+    stride 2 and 1, odd pictures, halo rows and rows past the last pixel zero-filled through the buffer descriptor's bounds.  Against fp64 as the
+    direct kernel (2e-5).  yv3_conv2d_launches counts the split."""
     mode = _ffi.F32
     lib = _ffi.lib()
     g = torch.Generator().manual_seed(cin + cout + H + B)
     if bn:
-        m = _rand_cbr(cin, cout, 1, 1, seed=cin + cout + H).cuda()
+        m = _rand_cbr(cin, cout, k, stride, seed=cin + cout + H).cuda()
     else:
         m = torch.nn.Conv2d(cin, cout, 1, 1, 0, bias=True)
         with torch.no_grad():
             m.weight.copy_(torch.rand(m.weight.shape, generator=g) - 0.5); m.bias.copy_(torch.rand(cout, generator=g) - 0.5)
         m = m.cuda().eval()
-    sp = arch.ConvSpec("t", cin, cout, 1, 1, bn, False)
+    sp = arch.ConvSpec("t", cin, cout, k, stride, bn, False)
     pc = engine.pack_conv(m, sp, mode)
     x = torch.rand(B, H, W, cin, generator=g) * 2 - 0.5
     xg = x.cuda()
-    M = B * H * W
+    Ho, Wo = engine.out_hw(H, W, k, stride)
+    M = B * Ho * Wo
 
     def run(t0, t1):
         buf = torch.full((M * cout + 4096,), float("nan"), device="cuda")
-        y = buf[:M * cout].view(B, H, W, cout)
+        y = buf[:M * cout].view(B, Ho, Wo, cout)
         d = engine.make_desc(pc, xg, y, B, H, W, None, dtype=mode)
         d.tune[0], d.tune[1] = t0, t1
+        n = lib.yv3_conv2d_launches(d)
         _ffi.check(lib.yv3_conv2d(d, _ffi.stream_ptr()))
         torch.cuda.synchronize()
         assert torch.isfinite(y).all(), "an output element was not written"
         assert torch.isnan(buf[M * cout:]).all(), "a store went past the last pixel"
-        return y
-    tiles = run(13, 0)
+        return y, n
+    tiles, n_tiles = run(13, 0)
+    assert n_tiles == 1
     for t0, t1 in ((14, 3), (14, 0), (0, 0)):
-        assert torch.equal(run(t0, t1), tiles), "tune %d,%d differs from the tiles" % (t0, t1)
+        y, n = run(t0, t1)
+        assert torch.equal(y, tiles), "tune %d,%d differs from the tiles" % (t0, t1)
+        assert n in (1, 2) and (n == 1 or (t1 == 0))
     with torch.no_grad():
-        xr = x.permute(0, 3, 1, 2).double()
         if bn:
             ref = _ref_cbr(m.cpu(), x.permute(0, 3, 1, 2))
         else:
-            ref = torch.nn.functional.conv2d(xr, m.weight.detach().cpu().double(), m.bias.detach().cpu().double())
-    assert_close_rel(tiles.permute(0, 3, 1, 2).cpu(), ref, 2e-5, "1x1 fp32 %s" % ((cin, cout, B, H, W),))
+            ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), m.weight.detach().cpu().double(), m.bias.detach().cpu().double())
+    assert_close_rel(tiles.permute(0, 3, 1, 2).cpu(), ref, 2e-5, "fp32 conv %s" % ((cin, cout, B, H, W, k, stride),))
 
 
 def test_eval_letterbox_and_scale_vs_oracle():

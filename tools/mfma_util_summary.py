@@ -46,6 +46,7 @@ def main():
                "conv_front" if "front" in n else "conv_res64" if "conv_res64" in n else "conv_1x1" if "conv1x1" in n else
                "conv_wino4_f32_kernel (exact fp32, Winograd F(4x4,3x3) GEMM stage + fold)" if "conv_wino4" in n else
                "wino4_input_f32_kernel (F(4x4,3x3) input transform)" if "wino4_input" in n else
+               "conv_gemm1x1_f32_kernel (exact fp32, plain 1x1 layers, persistent DMA-fed GEMM)" if "conv_gemm1x1" in n else
                "conv_igemm_f32_kernel" if "conv_igemm" in n else "conv0" if "conv0" in n else
                "postproc" if any(k in n for k in ("filter_kernel", "rank_kernel", "rank_seg_kernel", "segpart_kernel", "mask_kernel", "scan_kernel", "compact_kernel", "zero_kernel")) else None)
         if key is None or di not in dur:

@@ -21,7 +21,7 @@ out = {}
 F32R6 = len(sys.argv) > 5 and sys.argv[5] == "f32r6"
 PER_STEP = {"conv_wino4": 31, "wino4_input": 31, "conv_igemm": 40} if F32R6 else {}
 for fam, key in (("wino_input_kernel", "wino_input"), ("wino4_input_f32_kernel", "wino4_input"), ("conv_wino4_f32_kernel", "conv_wino4"),
-                 ("conv_planes_kernel", "conv_planes"), ("conv_igemm_f32_kernel", "conv_igemm"), ("conv0_kernel", "conv0"),
+                 ("conv_planes_kernel", "conv_planes"), ("conv_igemm_f32_kernel", "conv_igemm"), ("conv_gemm1x1_f32_kernel", "conv_gemm1x1"), ("conv0_kernel", "conv0"),
                  ("conv_front_kernel", "conv_front"), ("conv_res64_kernel", "conv_res64"), ("decode_kernel", "decode")):
     f, w = family(fetch, key), family(write, key)
     if not f: continue

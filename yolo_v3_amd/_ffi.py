@@ -62,6 +62,7 @@ _SIGNATURES = {
     "yv3_res_block64_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "yv3_conv2d": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "yv3_conv2d_form": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "yv3_conv2d_launches": (c_int, [ctypes.POINTER(ConvDesc)]),
     "yv3_conv2d_sequence": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
     "yv3_decode": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float), c_float, c_void_p, c_longlong,
                            c_int, c_int, c_int, c_int, c_void_p]),

@@ -4,6 +4,7 @@
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s);
 int yv3_conv2d_planes(const yv3_conv_desc* d, int np, hipStream_t s);
 int yv3_conv2d_f32_form(const yv3_conv_desc* d);
+int yv3_conv2d_f32_launches(const yv3_conv_desc* d);      // (direct form only)
 int yv3_conv2d_planes_form(const yv3_conv_desc* d, int np);
 
 extern "C" int yv3_version(void) { return YV3_VERSION; }
@@ -57,6 +58,13 @@ extern "C" int yv3_conv2d_form(const yv3_conv_desc* d) {
     if (d->dtype == YV3_F32_F16X2) return yv3_conv2d_planes_form(d, 2);
     if (d->dtype == YV3_F32_BF16X3 || d->dtype == YV3_BF16) return YV3_FORM_DIRECT;
     return YV3_EDTYPE;
+}
+
+extern "C" int yv3_conv2d_launches(const yv3_conv_desc* d) {
+    const int form = yv3_conv2d_form(d);
+    if (form < 0) return form;
+    if (form != YV3_FORM_DIRECT) return 2;
+    return d->dtype == YV3_F32 ? yv3_conv2d_f32_launches(d) : 1;
 }
 
 extern "C" int yv3_conv2d_sequence(const yv3_conv_desc* descs, int n, void* stream) {

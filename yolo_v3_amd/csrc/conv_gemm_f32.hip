@@ -36,6 +36,9 @@ struct Gemm1Params {
     int ntiles;              // all tiles
     int act;
     unsigned x_bytes, w_bytes, y_bytes;
+    // K3 (3x3, pad 1): input picture, output grid, stride; K = 9 cin, k = (kh, kw, cin) as conv_igemm_f32.hip
+    int H, W, Cin, Ho, Wo, stride;
+    int cch;                 // cin / 32
 };
 
 constexpr int G1_NST = 3;        // ring stages
@@ -43,7 +46,11 @@ template <int N> __device__ __forceinline__ void g1_wait_vmcnt() { asm volatile(
 __device__ __forceinline__ int g1_swz(int row) { return (row >> 1) & 7; }
 
 // WM x WN waves, wave tile 64 (pixels) x 32 (channels): workgroup tile BM = 64 WM, BN = 32 WN
-template <int WM, int WN>
+// K3: 3x3 / pad 1 layer (any stride) as an implicit GEMM: the A row of output pixel (b, ho, wo) and chunk (kh, kw, c0) is the 128 contiguous
+// bytes of input pixel (ho s + kh - 1, wo s + kw - 1) at channel c0 -- one request address per row and TAP (recomputed when the tap
+// changes, every cin / 32 chunks), the channel chunk in the scalar offset; halo rows and rows past the last pixel get an offset outside the
+// buffer descriptor: the hardware fills their LDS rows with zeros
+template <int WM, int WN, bool K3>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_gemm1x1_f32_kernel(const Gemm1Params p) {
     constexpr int NW = WM * WN, BM = 64 * WM, BN = 32 * WN;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
@@ -75,15 +82,42 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_gemm1x1_f32_kernel(const
     unsigned a_voff[PA], b_voff[PB];
     const int prow = lane >> 3, pslot = lane & 7;
     auto tile_origin = [&](int t, int& m0, int& n0) { n0 = (t % p.ntn) * BN; m0 = (t / p.ntn) * BM; };
-    auto producer_tile = [&]() {                                            // bases of tile pf_t
-        int m0, n0; tile_origin(pf_t, m0, n0);
-        a_soff = (unsigned)m0 * (unsigned)p.K * 4u;
-        b_soff = (unsigned)n0 * (unsigned)p.K * 4u;
+    unsigned a_pix[K3 ? PA : 1];                                            // K3: byte offset of input pixel (hi0, wi0) = (ho s - 1, wo s - 1), modulo 2^32
+    int a_hi[K3 ? PA : 1], a_wi[K3 ? PA : 1];                               //     hi0, wi0; hi0 = INT_MIN / 2: no such row (past the last pixel)
+    int pf_kh = 0, pf_kw = 0, pf_cc = 0;                                    // K3: tap and channel chunk of the chunk being requested
+    auto producer_tap = [&]() {                                             // K3: request addresses of tap (pf_kh, pf_kw)
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int r = 8 * (wid * PA + i) + prow;
-            const int rr = min(m0 + r, p.M - 1) - m0;                       // (rows past the last pixel re-read it; never stored)
-            a_voff[i] = (unsigned)rr * (unsigned)p.K * 4u + (unsigned)((pslot ^ g1_swz(r)) << 4);
+            const bool ok = (unsigned)(a_hi[i] + pf_kh) < (unsigned)p.H && (unsigned)(a_wi[i] + pf_kw) < (unsigned)p.W;
+            a_voff[i] = ok ? a_pix[i] + (unsigned)((pf_kh * p.W + pf_kw) * p.Cin * 4) + (unsigned)((pslot ^ g1_swz(r)) << 4) : 0xffffff00u;
+        }
+    };
+    auto producer_tile = [&]() {                                            // bases of tile pf_t
+        int m0, n0; tile_origin(pf_t, m0, n0);
+        b_soff = (unsigned)n0 * (unsigned)p.K * 4u;
+        if constexpr (K3) {
+            a_soff = 0; pf_kh = pf_kw = pf_cc = 0;
+            const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int m = m0 + 8 * (wid * PA + i) + prow;
+                const int b = m / HoWo, rem = m - b * HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                a_hi[i] = m < p.M ? ho * p.stride - 1 : -0x40000000; a_wi[i] = wo * p.stride - 1;
+                // ((b H + hi) W + wi) cin 4 of a valid tap is < 2^32 (host check); hi0 / wi0 = -1 make the base "negative" by at most
+                // (W + 1) cin 4: base + tap offset in 32-bit wrap-around arithmetic
+                a_pix[i] = (unsigned)((b * p.H + ho * p.stride - 1) * p.W + a_wi[i]) * (unsigned)p.Cin * 4u;
+            }
+            producer_tap();
+        } else {
+            a_soff = (unsigned)m0 * (unsigned)p.K * 4u;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int r = 8 * (wid * PA + i) + prow;
+                const int rr = min(m0 + r, p.M - 1) - m0;                   // (rows past the last pixel re-read it; never stored)
+                a_voff[i] = (unsigned)rr * (unsigned)p.K * 4u + (unsigned)((pslot ^ g1_swz(r)) << 4);
+            }
         }
     };
 #pragma unroll
@@ -105,7 +139,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_gemm1x1_f32_kernel(const
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, G1_LPTR(st + A_BYTES + (wid * PB + i) * 1024), 16, vo, b_soff, 0, 0);
         }
         if (pf_left > 0) {
-            if (++pf_c < p.nch) { a_soff += 128; b_soff += 128; }
+            if (++pf_c < p.nch) {
+                b_soff += 128;
+                if constexpr (K3) {
+                    if (++pf_cc < p.cch) a_soff += 128;
+                    else { pf_cc = 0; a_soff = 0; if (++pf_kw == 3) { pf_kw = 0; ++pf_kh; } producer_tap(); }
+                } else a_soff += 128;
+            }
             else if (--pf_left > 0) { pf_c = 0; pf_t += L; producer_tile(); }
             else { pf_c = p.nch - 1; }                                       // the very last chunk stays the one repeated
         }
@@ -237,46 +277,71 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_gemm1x1_f32_kernel(const
 
 }  // namespace
 
-// Does the persistent GEMM take this fp32 descriptor?  Plain 1x1 / stride-1 layers without residual whose tiles fill at least one round of
-// the chip (tune[0] == 13: never, 14: whenever the shape fits)
+// Does the persistent GEMM take this fp32 descriptor?  Plain 1x1 / stride-1 layers and 3x3 layers (any stride; the caller has ruled the
+// Winograd forms out) without residual or upsample operand whose tiles fill at least one round of the chip (tune[0] == 13: never, 14:
+// whenever the shape fits)
 static void gemm1_tiling(const yv3_conv_desc* d, int* bm, int* bn) { const bool wide = d->cout % 128 == 0; *bm = wide ? 128 : 256; *bn = wide ? 128 : 64; }
 bool yv3_gemm1x1_f32_takes(const yv3_conv_desc* d) {
-    if (d->k != 1 || d->stride != 1 || d->cin_up || d->residual || d->cin % 32 || d->cout % 64 || d->cout > 1024 || d->cout_pad != d->cout || d->tune[0] == 13) return false;
-    const long long M = (long long)d->B * d->H * d->W;
-    if (M * d->cin * 4 > 0xffffffffLL || M * d->cout * 4 > 0xffffffffLL || (long long)d->cout * d->cin * 4 > 0xffffffffLL) return false;
+    // (3x3 layers: built, bit-identical and measured -- 113-122 TFLOP/s where the 128x128 eight-wave tiles give 116-124: the long K loops
+    // of these layers amortise a tile's prologue and epilogue anyway, profiles/r06ag_gemm_k3_stride2_ab.txt -- taken with tune[0] == 14 only)
+    const bool k1 = d->k == 1 && d->stride == 1, k3 = d->k == 3 && d->cout % 128 == 0 && d->tune[0] == 14;
+    if (!(k1 || k3) || d->cin_up || d->residual || d->cin % 32 || d->cout % 64 || d->cout > 1024 || d->cout_pad != d->cout || d->tune[0] == 13) return false;
+    const int pad = (d->k - 1) / 2;
+    const long long Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
+    const long long M = (long long)d->B * Ho * Wo;
+    if ((long long)d->B * d->H * d->W * d->cin * 4 > 0xfffffe00LL || M * d->cout * 4 > 0xffffffffLL || (long long)d->cout * d->cin * d->k * d->k * 4 > 0xffffffffLL) return false;
     int bm, bn; gemm1_tiling(d, &bm, &bn);
     const long long tiles = ((M + bm - 1) / bm) * (d->cout / bn);
     return d->tune[0] == 14 || tiles >= (long long)yv3_num_cu();
 }
 
-// Launches the GEMM on pixel rows [0, *rows_done): whole rounds of the chip (one tile per CU and round) -- plus the last, partial round when
-// it is more than half full.  The caller runs the remaining rows (< half a round of tiles) on conv_igemm_f32.hip's small tiles, which fill
-// the chip four to a CU and finish in a fraction of a round here: 1352 tiles = 5.28 rounds would cost 6 (same K order: same bits).
+// Pixel-row tiles that run on the GEMM: whole rounds of the chip, plus the last partial round when it is more than 0.85 full (a rest of
+// up to 0.85 rounds is cheaper on the small tiles, which fill the chip two to four to a CU)
+static long long gemm1_mtiles_here(const yv3_conv_desc* d, long long M, int bm, int bn) {
+    const int ncu = yv3_num_cu(), ntn = d->cout / bn;
+    const long long mt = (M + bm - 1) / bm;
+    if (d->tune[1] == 3) return mt;                                        // (every row here -- measurements)
+    const long long rounds = mt * ntn / ncu, rest = mt * ntn - rounds * ncu;
+    return rounds >= 1 && rest > 0 && 20 * rest <= 17 * ncu ? rounds * ncu / ntn : mt;
+}
+
+// Kernel launches of a descriptor yv3_gemm1x1_f32_takes says yes to (1, or 2 with rows left for the small tiles)
+int yv3_gemm1x1_f32_launches(const yv3_conv_desc* d) {
+    const int pad = (d->k - 1) / 2;
+    const long long Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
+    const long long M = (long long)d->B * Ho * Wo;
+    int bm, bn; gemm1_tiling(d, &bm, &bn);
+    return gemm1_mtiles_here(d, M, bm, bn) * bm < M ? 2 : 1;
+}
+
+// Launches the GEMM on output pixels [0, *rows_done): whole rounds of the chip (one tile per CU and round) -- plus the last, partial round when
+// it is more than half full.  The caller runs the remaining rows (< half a round of tiles) on conv_igemm_f32.hip's tiles, which fill
+// the chip two to four to a CU and finish in a fraction of a round here: 1352 tiles = 5.28 rounds would cost 6 (same K order: same bits).
 int yv3_conv2d_gemm1x1_f32(const yv3_conv_desc* d, hipStream_t s, long long* rows_done) {
     Gemm1Params p;
     p.x = (const float*)d->x; p.w = (const float*)d->w; p.alpha = d->alpha; p.beta = d->beta; p.y = (float*)d->y;
-    const long long M = (long long)d->B * d->H * d->W;
+    const int pad = (d->k - 1) / 2;
+    p.H = d->H; p.W = d->W; p.Cin = d->cin; p.stride = d->stride; p.cch = d->cin / 32;
+    p.Ho = (d->H + 2 * pad - d->k) / d->stride + 1; p.Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
+    const long long M = (long long)d->B * p.Ho * p.Wo;
     if (M > 0x7fffffffLL) return YV3_ESHAPE;
     int bm, bn; gemm1_tiling(d, &bm, &bn);
-    const int ncu = yv3_num_cu();
     const int ntn = d->cout / bn;
-    const long long mt = (M + bm - 1) / bm;
-    long long mt_run = mt;
-    if (d->tune[1] != 3) {                                                 // (tune[1] == 3: every row here -- measurements)
-        const long long rounds = mt * ntn / ncu, rest = mt * ntn - rounds * ncu;
-        if (rounds >= 1 && rest > 0 && 2 * rest <= ncu) mt_run = rounds * ncu / ntn;
-    }
+    const int ncu = yv3_num_cu();
+    const long long mt_run = gemm1_mtiles_here(d, M, bm, bn);
     const long long Mr = mt_run * bm < M ? mt_run * bm : M;
     *rows_done = Mr;
-    p.M = (int)Mr; p.K = d->cin; p.N = d->cout; p.nch = d->cin / 32; p.act = d->act;
-    p.x_bytes = (unsigned)(Mr * d->cin * 4); p.y_bytes = (unsigned)(Mr * d->cout * 4); p.w_bytes = (unsigned)((long long)d->cout * d->cin * 4);
+    p.M = (int)Mr; p.K = d->k * d->k * d->cin; p.N = d->cout; p.nch = p.K / 32; p.act = d->act;
+    p.x_bytes = (unsigned)((long long)d->B * d->H * d->W * d->cin * 4); p.y_bytes = (unsigned)(Mr * d->cout * 4);
+    p.w_bytes = (unsigned)((long long)d->cout * p.K * 4);
     p.ntn = ntn;
     const long long tiles = mt_run * ntn;
     p.ntiles = (int)tiles;
     const int grid = (int)(tiles < ncu ? (tiles + 7) / 8 * 8 : ncu);
     const size_t lds = (size_t)G1_NST * (bm + bn) * 128 + 2 * d->cout * sizeof(float);
-    if (bn == 128) hipLaunchKernelGGL((conv_gemm1x1_f32_kernel<2, 4>), dim3(grid), dim3(512), lds, s, p);
-    else           hipLaunchKernelGGL((conv_gemm1x1_f32_kernel<4, 2>), dim3(grid), dim3(512), lds, s, p);
+    if (d->k == 3)      hipLaunchKernelGGL((conv_gemm1x1_f32_kernel<2, 4, true>), dim3(grid), dim3(512), lds, s, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv_gemm1x1_f32_kernel<2, 4, false>), dim3(grid), dim3(512), lds, s, p);
+    else                hipLaunchKernelGGL((conv_gemm1x1_f32_kernel<4, 2, false>), dim3(grid), dim3(512), lds, s, p);
     YV3_CHECK_LAUNCH();
     return 0;
 }

@@ -39,6 +39,7 @@ struct ConvParams {
     int cchunks;       // Cin / 32
     int nk;            // K / 32
     int ntiles;        // N tiles
+    int m_base;        // first output pixel of this launch (rows below it were computed by another launch: conv_gemm_f32.hip)
     // Winograd launches (WINO): rows are 2x2 output tiles, position xi's operand matrix starts xi * xi_stride floats into x
     long long xi_stride;
     int wH, wW, wth, wtw;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_igemm_f32_kernel(cons
 
     const int bid = yv3_xcd_remap(blockIdx.x, gridDim.x);
     const int n0 = (bid % p.ntiles) * BN;
-    const int m0 = (bid / p.ntiles) * BM;
+    const int m0 = (bid / p.ntiles) * BM + p.m_base;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_igemm_f32_kernel(cons
 
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, bool k3, bool dual, hipStream_t s, bool pin) {
-    const int mtiles = (p.M + BM - 1) / BM;
+    const int mtiles = (p.M - p.m_base + BM - 1) / BM;
     const dim3 grid((unsigned)(mtiles * p.ntiles));
     const size_t pipe = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     const size_t epi = (size_t)WM * WN * (BM / WM) * (BN / WN + 4) * sizeof(float);
@@ -426,6 +427,7 @@ static int launch_wino_f32(const yv3_conv_desc* d, ConvParams p, hipStream_t s) 
 int yv3_conv2d_wino4_f32(const yv3_conv_desc* d, hipStream_t s);
 int yv3_conv2d_gemm1x1_f32(const yv3_conv_desc* d, hipStream_t s, long long* rows_done);      // csrc/conv_gemm_f32.hip: plain 1x1 layers, persistent DMA-fed GEMM
 bool yv3_gemm1x1_f32_takes(const yv3_conv_desc* d);
+int yv3_gemm1x1_f32_launches(const yv3_conv_desc* d);
 long long yv3_wino4_f32_workgroups(const yv3_conv_desc* d);
 bool yv3_wino4_f32_pays(const yv3_conv_desc* d);
 
@@ -455,12 +457,15 @@ int yv3_conv2d_f32_form(const yv3_conv_desc* d) {
     return (!d->wino_ws || d->wino_ws_bytes < (size_t)16 * T2 * d->cin * sizeof(float)) ? YV3_EWORKSPACE : YV3_FORM_WINOGRAD;
 }
 
+// kernel launches of a descriptor that takes the direct form (exported through yv3_conv2d_launches)
+int yv3_conv2d_f32_launches(const yv3_conv_desc* d) { return yv3_gemm1x1_f32_takes(d) ? yv3_gemm1x1_f32_launches(d) : 1; }
+
 int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     ConvParams p;
     p.x = (const float*)d->x; p.x2 = (const float*)d->x2; p.w = (const float*)d->w;
     p.alpha = d->alpha; p.beta = d->beta; p.res = (const float*)d->residual; p.y = (float*)d->y;
     p.H = d->H; p.W = d->W; p.Cin = d->cin; p.Cup = d->cin_up; p.Cout = d->cout;
-    p.stride = d->stride; p.act = d->act;
+    p.stride = d->stride; p.act = d->act; p.m_base = 0;
     const int pad = (d->k - 1) / 2;
     p.Ho = (d->H + 2 * pad - d->k) / d->stride + 1;
     p.Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
@@ -477,17 +482,16 @@ int yv3_conv2d_f32(const yv3_conv_desc* d, hipStream_t s) {
     if (form == YV3_FORM_WINOGRAD4) return yv3_conv2d_wino4_f32(d, s);
     if (form == YV3_FORM_WINOGRAD) return launch_wino_f32(d, p, s);
     if (yv3_gemm1x1_f32_takes(d)) {
-        // plain 1x1 layer: whole rounds of the chip on the persistent GEMM, the rest (< half a round of its tiles) on the small tiles below
+        // plain 1x1 / 3x3 layer: whole rounds of the chip on the persistent GEMM, the rest (< half a round of its tiles) on the tiles below
         // (same K order per output element: same bits whoever computes a row)
         long long done = 0;
         const int rc = yv3_conv2d_gemm1x1_f32(d, s, &done);
         if (rc || done >= M) return rc;
-        p.x += done * d->cin; p.y += done * d->cout;
-        p.M = (int)(M - done);
-        p.H = 1; p.W = p.M; p.Ho = 1; p.Wo = p.M;                              // (a 1x1 layer's rows are independent: the rest as one image of M' x 1 pixels)
+        p.m_base = (int)done;
         const int np1 = d->cout_pad;
-        if (np1 % 128 == 0 || np1 % 64 == 0) { p.ntiles = np1 / 64; return np1 % 128 == 0 ? launch<64, 64, 2, 2>(p, false, false, s, pin) : launch<128, 64, 2, 2>(p, false, false, s, pin); }
-        return YV3_ESHAPE;
+        if (k3) { p.ntiles = np1 / 128; return launch<128, 128, 4, 2>(p, true, false, s, pin); }
+        p.ntiles = np1 / 64;
+        return np1 % 128 == 0 ? launch<64, 64, 2, 2>(p, false, false, s, pin) : launch<128, 64, 2, 2>(p, false, false, s, pin);
     }
 
     // Tile selection: widest N tile the layer fills; for launches that would leave most of the

@@ -463,6 +463,18 @@ class Plan:
     def bytes_allocated(self):
         return sum(t.numel() * t.element_size() for t in self._keep)
 
+    def launches(self):
+        """Kernel launches per descriptor of the launch sequence (``yv3_conv2d_launches``): 2 for the Winograd forms and for a 1x1 layer that
+        runs as persistent GEMM + small tiles; profiling tools map a kernel trace to layers with it."""
+        lib = _ffi.lib()
+        out = []
+        for j in range(self.first_desc, self.n_desc):
+            n = lib.yv3_conv2d_launches(ctypes.byref(self.descs[j]))
+            if n < 0:
+                _ffi.check(n, "yv3_conv2d_launches")
+            out.append(int(n))
+        return out
+
     def forms(self):
         """Per descriptor of the launch sequence (``descs[first_desc:]``): (conv spec index, form) with form = 0 direct /
         1 Winograd F(2x2,3x3) / 2 Winograd F(4x4,3x3) (exact-fp32 mode), as the library decides it on the current device
