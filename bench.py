@@ -1019,7 +1019,7 @@ def main():
                 nbox = int(res[0].shape[0]) if res else 0
                 del d
             out.setdefault("configs", {})["0"] = {"workload": "BASELINE configs[0]: dog-cycle-car.png letterboxed to 416x416 (fixture), bs=1, SW-1 weights, "
-                                                              "conf=0.5 nms=0.4, f32h2; latency of the whole detect call (kernels + D2H + list conversion), mean of 50",
+                                                              "conf=0.5 nms=0.4, math mode of this run (%s); latency of the whole detect call (kernels + D2H + list conversion), mean of 50" % args.dtype,
                                                   "gpu_ms_per_img": lat, "boxes": nbox}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

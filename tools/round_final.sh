@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence run on one MI355X box: bash tools/round_final.sh TAG   (outputs gpurun_out/TAG_*; see profiles/README.md)
 # bench.py's default (= the headline) is the exact-fp32 mode since round 6; the other modes are profiled by name.
-T=${1:-r06z}
+T=${1:-r06zz}
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 bash tools/gpu.sh $T tests
 bash tools/gpu.sh $T bench

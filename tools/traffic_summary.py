@@ -28,6 +28,8 @@ for fam, key in (("wino_input_kernel", "wino_input"), ("wino4_input_f32_kernel",
     n = len(f)
     # last `launches` of a step: use all launches / steps
     lps = PER_STEP.get(key) or (launches_per_step if "conv_planes" in key or "igemm" in key else {"conv0": 1, "conv_front": 1, "conv_res64": 1, "decode": 3}.get(key, 1))
+    if n % steps == 0:
+        lps = n // steps                      # (the profiled run's step count is known: dispatches per step follow -- a layer may be two launches since round 6)
     per_step_f = sum(f) / (n / lps) if n else 0
     per_step_w = sum(w) / (len(w) / lps) if w else 0
     out[fam] = {"launches_profiled": n, "launches_per_step": lps, "fetch_KiB_per_step_raw": per_step_f, "write_KiB_per_step": per_step_w,
