@@ -55,10 +55,8 @@ for arg in sys.argv[1:]:
                 _ffi.check(lib.yv3_conv2d(d, st))
             e1.record(); torch.cuda.synchronize()
             best[i] = min(best[i], e0.elapsed_time(e1) / iters)
-    again = [bool(torch.equal(y, y.clone())) for y in ys]
     th = (H + 3) // 4
     items = ((B * th * th + 31) // 32) * (cout // 64)
-    fl = 2.0 * B * H * H * cout * cin * 9
     print("%-4s B=%3d items %5d (%.3f rounds):" % (name, B, items, items / 512) +
           "".join("  %s %.4f ms err %.1e dif %.1e" % (v[0], t, e, df) for v, t, e, df in zip(variants, best, errs, dif)) +
           "  status %d flags_nonzero %d" % (int(status.item()), int((ws[-2600:] != 0).sum().item())))

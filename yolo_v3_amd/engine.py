@@ -790,7 +790,8 @@ class Engine:
         ``forward_cat``, ``detect(is_eval=True)``, ``predict_and_process`` -- can hand out saturated values.
         ``net.async_forward = True`` restores the fully asynchronous behaviour (the flag of a call is then examined
         at the start of the next call on the same plan); `Detector` checks the flag with its single D2H copy of the
-        box counts either way.  The other math modes have fp32's exponent range and never wait."""
+        box counts either way.  F32X3 has fp32's exponent range and never waits; exact F32 waits the same way while its F(4x4,3x3) stage may use the
+        even schedule (``checks_status``: a hand-over time-out on a shared GPU is the one status it can report; not under ``net.stream_k = False``)."""
         x = self.prepare_input(x)
         with torch.cuda.device(x.device):
             self.ensure_packed()
