@@ -41,7 +41,10 @@ struct Gemm1Params {
     int cch;                 // cin / 32
 };
 
-constexpr int G1_NST = 3;        // ring stages
+#ifndef G1_NST_
+#define G1_NST_ 3
+#endif
+constexpr int G1_NST = G1_NST_;  // ring stages (4 -- 128 KB, 128x128 tile only -- measured: +-0.5 %, profiles/r06am_gemm1x1_ring_depth4_ab.txt)
 template <int N> __device__ __forceinline__ void g1_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ int g1_swz(int row) { return (row >> 1) & 7; }
 
