@@ -298,14 +298,15 @@ bool yv3_gemm1x1_f32_takes(const yv3_conv_desc* d) {
     return d->tune[0] == 14 || tiles >= (long long)yv3_num_cu();
 }
 
-// Pixel-row tiles that run on the GEMM: whole rounds of the chip, plus the last partial round when it is more than 0.85 full (a rest of
-// up to 0.85 rounds is cheaper on the small tiles, which fill the chip two to four to a CU)
+// Pixel-row tiles that run on the GEMM: whole rounds of the chip, plus the last partial round when it is more than half full (measured,
+// profiles/r06am_gemm1x1_ring_depth4_ab.txt: a rest of 0.28 / 0.33 rounds is cheaper on the small tiles, which fill the chip two to four to a
+// CU -- 0.109 vs 0.111 ms, 0.106 vs 0.125; a rest of 0.64 rounds is cheaper as one more round here: 0.100 vs 0.103, 0.054 vs 0.057)
 static long long gemm1_mtiles_here(const yv3_conv_desc* d, long long M, int bm, int bn) {
     const int ncu = yv3_num_cu(), ntn = d->cout / bn;
     const long long mt = (M + bm - 1) / bm;
     if (d->tune[1] == 3) return mt;                                        // (every row here -- measurements)
     const long long rounds = mt * ntn / ncu, rest = mt * ntn - rounds * ncu;
-    return rounds >= 1 && rest > 0 && 20 * rest <= 17 * ncu ? rounds * ncu / ntn : mt;
+    return rounds >= 1 && rest > 0 && 2 * rest <= ncu ? rounds * ncu / ntn : mt;
 }
 
 // Kernel launches of a descriptor yv3_gemm1x1_f32_takes says yes to (1, or 2 with rows left for the small tiles)
