@@ -1,9 +1,10 @@
-// 1x1 convolution (stride 1, no residual, no upsample operand) of the exact-fp32 mode as a PERSISTENT, DMA-fed GEMM (round 6).
+// 1x1 convolution (stride 1, no residual, no upsample operand) of the exact-fp32 mode as a PERSISTENT, DMA-fed GEMM (round 6); the same
+// kernel carries a 3x3 operand path (K3, below) that is tested but not dispatched.
 //
 //   y[m][n] = act( sum_k x[m][k] * w[n][k] * alpha[n] + beta[n] )        m = pixel (NHWC: a row of cin floats), n = output channel
 //
-// conv_igemm_f32.hip runs these layers on 64x64 tiles, four workgroups per CU, operands staged global -> registers -> LDS: 102-110 TFLOP/s
-// of the 157 fp32 MFMA peak (profiles/r06z_layers.txt).  With K = cin of only 8-32 chunks a tile's index arithmetic, first-load latency and
+// conv_igemm_f32.hip runs these layers on 64x64 tiles, four workgroups per CU, operands staged global -> registers -> LDS: 74-110 TFLOP/s
+// of the 157 fp32 MFMA peak (profiles/r06z_layers.txt; 136-144 is what the instruction gives on random data).  With K = cin of only 8-32 chunks a tile's index arithmetic, first-load latency and
 // epilogue are a third of its life, and the four residents of a CU go through those phases together.  Here:
 //   * one workgroup per CU that walks its share of the tiles (XCD-contiguous ranges, n fastest: the tiles of one pixel block follow each
 //     other behind one L2);
@@ -13,8 +14,11 @@
 //     chunks are in LDS before the current tile's epilogue starts;
 //   * eight waves, 64x32 wave tiles (two 32x32 accumulator blocks sharing the weight fragment), one barrier per chunk, the next
 //     chunk's fragments read under this chunk's 32 MFMAs;
-//   * the epilogue stores straight from the accumulators (a wave instruction writes two rows x 128 contiguous bytes): ~130 instructions
-//     per wave and tile, no LDS round trip, no barrier.
+//   * the epilogue stores straight from the accumulators by buffer stores (a wave instruction writes two rows x 128 contiguous bytes; rows
+//     past the last pixel fall outside the descriptor), scale / shift from LDS: no loads in the in-order vmcnt queue, no barrier;
+//   * whole rounds of the chip only: the rows of a last round that is at most half full go to conv_igemm_f32.hip's small tiles.
+// Measured per layer incl. that rest launch (profiles/r06ae_*, r06am_*): 256->128 @52 0.122 -> 0.109 ms, 512->256 @26 0.107 -> 0.100,
+// 1024->512 @13 0.108 -> 0.105, 128->64 @104 0.154 -> 0.118; two-lane headline +1.1 % (profiles/r06an_*).
 // K order per output element = conv_igemm_f32.hip's (chunk by chunk, k pairs (8 kk + t, 8 kk + 4 + t)): bit-identical results.
 //
 // Replaces reference darknet.py:43-44 (conv_bn_relu.forward, kernel 1) for the layers the launch rule below takes.
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_gemm1x1_f32_kernel(const
     int my = t0 + loc < t1 ? (t1 - t0 - loc + L - 1) / L : 0;              // tiles of this workgroup: t0 + loc + j L
     if (my == 0) return;
 
-    // scale / shift of all N <= 512 channels into LDS once (behind the ring): the epilogue must not put loads into the vector-memory queue --
+    // scale / shift of all N <= 1024 channels into LDS once (behind the ring): the epilogue must not put loads into the vector-memory queue --
     // vmcnt counts in issue order, and a wait for them would also wait for every operand request in flight
     float* const ab = reinterpret_cast<float*>(lds + G1_NST * STAGE);     // [2][N]
     for (int i = tid; i < p.N; i += 64 * NW) { ab[i] = p.alpha ? p.alpha[i] : 1.f; ab[p.N + i] = p.beta[i]; }
